@@ -1,0 +1,179 @@
+/*
+ * af_noise.h — the engine's counter-based noise source ("tier B" generator).
+ *
+ * The reference (genData/player.py:240,270,275,278,102,125) draws its Dirichlet
+ * noise and tie-breaks from the process-global, serial MT19937 streams of
+ * numpy and Python `random`.  A serial stream cannot be reproduced by thousands
+ * of concurrent games on a GPU, so the engine DEFINES its own generator here:
+ * Philox4x32-10 keyed by (seed, game id) and indexed by
+ * (select counter, episode, stream|cell, iteration).  The sampling ALGORITHMS
+ * are the reference's (numpy legacy gamma-rejection for Dirichlet(alpha<1),
+ * uniform index draws, inverse-cdf move sampling); only the uniform source and
+ * the log/exp implementation are the build's own.
+ *
+ * Everything in this header is written with plain IEEE-754 +,-,*,/ (no fma, no
+ * libm) so that gcc on the host and hipcc on gfx950 produce bit-identical
+ * results when both compile with -ffp-contract=off and without fast-math.
+ * It is included by the HIP engine (product) and by oracle/af_oracle.c (the
+ * checker) — it is a specification shared by both, like a file format.
+ */
+#ifndef AF_NOISE_H
+#define AF_NOISE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define AF_HD __host__ __device__ static inline
+#else
+#define AF_HD static inline
+#endif
+
+/* ---- noise streams (third counter word = stream << 24 | index) ---- */
+#define AF_STREAM_GAMMA   0u  /* index = cell, iteration = rejection round        */
+#define AF_STREAM_PICK    1u  /* uniform pick among select candidates             */
+#define AF_STREAM_BEST    2u  /* per-ply tie-break among most-visited (random.choice) */
+#define AF_STREAM_MOVE    3u  /* per-ply move sample (np.random.choice(L,p))      */
+
+typedef struct { uint32_t v[4]; } af_u32x4;
+
+AF_HD uint32_t af_mulhi32(uint32_t a, uint32_t b) {
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+
+/* Philox4x32-10 (Salmon et al., SC'11).  ctr[4], key[2] -> 4 words. */
+AF_HD af_u32x4 af_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                             uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = af_mulhi32(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = af_mulhi32(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n1 = lo1;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        uint32_t n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    af_u32x4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+/* 53-bit uniform in [0,1) from two words — same construction as MT19937's
+ * genrand_res53 used by numpy's legacy double. */
+AF_HD double af_u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+/* per-game key */
+AF_HD uint32_t af_key0(uint64_t seed) { return (uint32_t)seed; }
+AF_HD uint32_t af_key1(uint64_t seed, uint32_t game_id) { return (uint32_t)(seed >> 32) + game_id; }
+
+/* ---- deterministic log / exp (plain-op, ~1e-15 relative) ---- */
+AF_HD double af_bits2d(uint64_t u) { union { uint64_t u; double d; } x; x.u = u; return x.d; }
+AF_HD uint64_t af_d2bits(double d) { union { uint64_t u; double d; } x; x.d = d; return x.u; }
+
+#define AF_NEG_HUGE (-1.0e300)
+
+/* natural log of a positive finite double; af_log(0) = AF_NEG_HUGE */
+AF_HD double af_log(double x) {
+    if (!(x > 0.0)) return AF_NEG_HUGE;
+    uint64_t b = af_d2bits(x);
+    int e = (int)(b >> 52);
+    if (e == 0) {                        /* subnormal: scale up by 2^54 */
+        x = x * 18014398509481984.0;
+        b = af_d2bits(x);
+        e = (int)(b >> 52) - 54;
+    }
+    e -= 1023;
+    uint64_t mant = b & 0x000FFFFFFFFFFFFFull;
+    double m = af_bits2d(mant | 0x3FF0000000000000ull);   /* [1,2) */
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }   /* [0.7071,1.4142] */
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (0.3999999999940941908 + w * (0.2222219843214978396 + w * 0.1531383769920937332));
+    double t2 = z * (0.6666666666666735130 + w * (0.2857142874366239149 + w * (0.1818357216161805012 + w * 0.1479819860511658591)));
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    double dk = (double)e;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+/* exp(x); returns 0 below ~-708, saturates above +709 */
+AF_HD double af_exp(double x) {
+    if (x < -708.0) return 0.0;
+    if (x > 709.0) x = 709.0;
+    const double inv_ln2 = 1.44269504088896338700e+00;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    double kf = x * inv_ln2;
+    int k = (int)(kf + (kf < 0.0 ? -0.5 : 0.5));
+    double dk = (double)k;
+    double hi = x - dk * ln2_hi;
+    double lo = dk * ln2_lo;
+    double r = hi - lo;
+    double t = r * r;
+    double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 +
+               t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    /* scale by 2^k in two exact steps (k in [-1022, 1023]) */
+    int k1 = k / 2, k2 = k - k1;
+    double s1 = af_bits2d((uint64_t)(k1 + 1023) << 52);
+    double s2 = af_bits2d((uint64_t)(k2 + 1023) << 52);
+    return (y * s1) * s2;
+}
+
+/* x^y for x >= 0 (x == 0 -> 0), via exp(y*log x) */
+AF_HD double af_pow(double x, double y) {
+    if (!(x > 0.0)) return 0.0;
+    return af_exp(y * af_log(x));
+}
+
+/* fp32 power used by the tier-B temperature policy (player.py:117) */
+AF_HD float af_powf(float x, float y) {
+    if (!(x > 0.0f)) return 0.0f;
+    return (float)af_exp((double)y * af_log((double)x));
+}
+
+/* ---- samplers ---- */
+
+/* One Gamma(alpha,1) variate, alpha < 1: numpy legacy_standard_gamma's
+ * rejection loop (restated in SURVEY.md §8a), uniforms taken from
+ * Philox(counter = (sel, episode, GAMMA<<24|cell, round)). */
+AF_HD double af_gamma_lt1(double alpha, uint32_t sel, uint32_t episode, uint32_t cell,
+                          uint32_t k0, uint32_t k1) {
+    const double inv_a = 1.0 / alpha;
+    const double one_m_a = 1.0 - alpha;
+    for (uint32_t it = 0;; ++it) {
+        af_u32x4 r = af_philox4x32(sel, episode, (AF_STREAM_GAMMA << 24) | cell, it, k0, k1);
+        double U = af_u53(r.v[0], r.v[1]);
+        double V = -af_log(1.0 - af_u53(r.v[2], r.v[3]));
+        if (U <= one_m_a) {
+            double X = af_pow(U, inv_a);
+            if (X <= V) return X;
+        } else {
+            double Y = -af_log((1.0 - U) / alpha);
+            double X = af_pow(one_m_a + alpha * Y, inv_a);
+            if (X <= V + Y) return X;
+        }
+        if (it == 0xFFFFu) return 0.0;   /* unreachable in practice; bounds the loop */
+    }
+}
+
+/* uniform index in [0,m): multiply-shift on one word; m == 1 -> 0 */
+AF_HD uint32_t af_pick(uint32_t m, uint32_t sel, uint32_t episode, uint32_t stream,
+                       uint32_t k0, uint32_t k1) {
+    if (m <= 1u) return 0u;
+    af_u32x4 r = af_philox4x32(sel, episode, stream << 24, 0u, k0, k1);
+    return af_mulhi32(r.v[0], m);
+}
+
+/* one uniform double for the per-ply move sample */
+AF_HD double af_uniform(uint32_t sel, uint32_t episode, uint32_t stream, uint32_t k0, uint32_t k1) {
+    af_u32x4 r = af_philox4x32(sel, episode, stream << 24, 0u, k0, k1);
+    return af_u53(r.v[0], r.v[1]);
+}
+
+#endif /* AF_NOISE_H */

@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by importing the UNMODIFIED
+reference from /root/reference (build container only; the reference never travels).
+
+    python tests/golden/make_golden.py
+
+What is recorded (data only — inputs and expected outputs):
+  rules.npz      utils.py known answers: boards -> state strings, is_game_over,
+                 get_legal_actions, board_to_inputs, step, construct_weights
+  mcts_*.npz     genData.player.Player driven under np.random.seed(s); random.seed(s)
+                 with the integer pseudo-net: per-ply states, actions, root
+                 visit-count vectors, policies, and the complete final tree
+                 (sum_n, n, w, dtype class of w, p per node)
+  run_*.npz      Player.run() episodes: the 5-tuples + main.gen_data's result code
+The pseudo-net (tests/pseudonet.py) is the build's own deterministic stand-in for
+ResNet.eval; it is handed to the reference through its pv_fn seam (player.py:24).
+"""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, "/root/reference")
+
+import config as refcfg            # noqa: E402  (reference)
+import utils as refutils           # noqa: E402  (reference)
+from genData.player import Player  # noqa: E402  (reference)
+
+import pseudonet                   # noqa: E402  (build's own)
+
+
+def mkcfg(**kw):
+    c = types.SimpleNamespace(**{k: getattr(refcfg, k) for k in dir(refcfg)
+                                 if not k.startswith("_") and k != "get_lr"})
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+CFG_KEYS = ["board_size", "goal", "simulation_per_step", "upper_simulation_per_step", "init_temp", "gamma",
+            "tau_decay_rate", "tau_decay_rate_r", "dirichlet_alpha", "c_puct"]
+
+
+def cfg_arrays(cfg):
+    return {"cfg_" + k: np.asarray(getattr(cfg, k)) for k in CFG_KEYS}
+
+
+def dump_tree(player, S):
+    C = S * S
+    keys = list(player.tree.keys())
+    n_nodes = len(keys)
+    sum_n = np.zeros(n_nodes, np.int32)
+    n = np.zeros((n_nodes, C), np.int32)
+    w = np.zeros((n_nodes, C), np.float64)
+    wf32 = np.zeros((n_nodes, C), np.uint8)
+    q = np.zeros((n_nodes, C), np.float64)
+    p = np.zeros((n_nodes, C), np.float32)
+    legal = np.zeros((n_nodes, C), np.uint8)
+    for k, key in enumerate(keys):
+        st = player.tree[key]
+        sum_n[k] = st.sum_n
+        for (i, j), a in st.a.items():
+            c = i * S + j
+            legal[k, c] = 1
+            n[k, c] = a.n
+            w[k, c] = float(a.w)
+            wf32[k, c] = isinstance(a.w, np.float32)
+            q[k, c] = float(a.q)
+            p[k, c] = a.p
+    return dict(tree_keys=np.array(keys), tree_sum_n=sum_n, tree_n=n, tree_w=w, tree_wf32=wf32, tree_q=q,
+                tree_p=p, tree_legal=legal)
+
+
+def gen_rules(path):
+    rng = np.random.RandomState(7)
+    boards, states, over, value, goals = [], [], [], [], []
+    cases = []
+    for S, goal in [(11, 5), (15, 5), (7, 4), (6, 4), (3, 3)]:
+        for t in range(60):
+            fill = rng.rand()
+            b = rng.choice([-1, 0, 1], size=(S, S), p=[fill / 2, 1 - fill, fill / 2]).astype(np.int8)
+            cases.append((b, goal))
+        # crafted lines in every direction, both colours, at edges, overlines, truncated windows
+        for colour in (1, -1):
+            for length in (goal - 1, goal, goal + 1):
+                for (di, dj) in [(1, 0), (0, 1), (1, 1), (-1, 1)]:
+                    for _ in range(3):
+                        b = np.zeros((S, S), np.int8)
+                        i0 = rng.randint(0, S)
+                        j0 = rng.randint(0, S)
+                        ok = True
+                        for k in range(length):
+                            i, j = i0 + di * k, j0 + dj * k
+                            if not (0 <= i < S and 0 <= j < S):
+                                ok = False
+                                break
+                            b[i, j] = colour
+                        if ok:
+                            cases.append((b, goal))
+        full = rng.choice([-1, 1], size=(S, S)).astype(np.int8)
+        cases.append((full, goal))
+        # full board without a line (stripe pattern) — draw
+        stripe = np.fromfunction(lambda i, j: ((i // 2 + j) % 2) * 2 - 1, (S, S)).astype(np.int8)
+        cases.append((stripe, goal))
+        both = np.zeros((S, S), np.int8)
+        if S >= goal + 1:
+            both[0, :goal] = -1
+            both[1, :goal] = 1
+            cases.append((both, goal))
+            cases.append((-both, goal))
+    rec = dict(S=[], goal=[], board=[], state=[], over=[], value=[], legal_count=[])
+    legal_cells, inputs, stepped = [], [], []
+    for b, goal in cases:
+        S = b.shape[0]
+        rec["S"].append(S)
+        rec["goal"].append(goal)
+        pad = np.zeros((15, 15), np.int8)
+        pad[:S, :S] = b
+        rec["board"].append(pad)
+        s = refutils.board_to_state(b)
+        assert (refutils.state_to_board(s, S) == b).all()
+        rec["state"].append(s)
+        o, v = refutils.is_game_over(b, goal)
+        rec["over"].append(o)
+        rec["value"].append(v)
+        la = refutils.get_legal_actions(b)
+        rec["legal_count"].append(len(la))
+        lc = np.full(225, -1, np.int32)
+        lc[:len(la)] = [i * S + j for i, j in la]
+        legal_cells.append(lc)
+        last = la[len(la) // 2] if la else None
+        x = refutils.board_to_inputs(b, last_action=last)
+        xp = np.zeros((3, 15, 15), np.float32)
+        xp[:, :S, :S] = x
+        inputs.append(xp)
+        sp = np.zeros((15, 15), np.int8)
+        if la:
+            sp[:S, :S] = refutils.step(b.copy(), la[0])
+        stepped.append(sp)
+    cw = {f"cw_{T}_{g}": refutils.construct_weights(T, gamma=g) for T in (1, 2, 5, 9, 26, 64, 121, 200)
+          for g in (0.94, 0.95)}
+    np.savez_compressed(path, S=np.array(rec["S"]), goal=np.array(rec["goal"]), board=np.array(rec["board"]),
+                        state=np.array(rec["state"]), over=np.array(rec["over"]), value=np.array(rec["value"]),
+                        legal_count=np.array(rec["legal_count"]), legal_cells=np.array(legal_cells),
+                        inputs=np.array(inputs), stepped=np.array(stepped), **cw)
+    print("rules:", len(cases), "cases")
+
+
+def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, random_a=False, reset_every=None):
+    cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper)
+    np.random.seed(seed)
+    random.seed(seed)
+    pl = Player(cfg, training=training, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak))
+    state = pl.get_init_state()
+    last, over, ply = None, False, 0
+    C = S * S
+    states, actions, lasts, visits, policies, has_pol, taus = [], [], [], [], [], [], []
+    while not over and ply < max_plies:
+        pol, act = pl.get_action(state, last_action=last, random_a=random_a)
+        node = pl.tree[state]
+        v = np.zeros(C, np.int32)
+        for (i, j), a in node.a.items():
+            v[i * S + j] = a.n
+        states.append(state)
+        actions.append(act[0] * S + act[1])
+        lasts.append(-1 if last is None else last[0] * S + last[1])
+        visits.append(v)
+        has_pol.append(pol is not None)
+        policies.append(np.zeros(C, np.float32) if pol is None else pol.reshape(-1))
+        taus.append(pl.tau)
+        board = refutils.step(refutils.state_to_board(state, S), act)
+        state = refutils.board_to_state(board)
+        over, _ = refutils.is_game_over(board, goal)
+        last = act
+        ply += 1
+    # position of both MT streams after the run (pins the number of draws consumed)
+    np_next = int(np.random.randint(0, 2 ** 32, dtype=np.uint64))
+    py_next = random.getrandbits(32)
+    out = dict(training=np.asarray(training), seed=np.asarray(seed), salt=np.asarray(salt), peak=np.asarray(peak),
+               random_a=np.asarray(random_a), states=np.array(states), actions=np.array(actions, np.int32),
+               lasts=np.array(lasts, np.int32), visits=np.array(visits), policies=np.array(policies),
+               has_policy=np.array(has_pol), taus=np.array(taus), np_next=np.asarray(np_next),
+               py_next=np.asarray(py_next), finished=np.asarray(over))
+    out.update(cfg_arrays(cfg))
+    out.update(dump_tree(pl, S))
+    np.savez_compressed(path, **out)
+    print(os.path.basename(path), "plies", ply, "nodes", len(pl.tree), "over", over)
+
+
+def gen_run(path, S, goal, sims, upper, seed, salt, peak, episodes):
+    cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper)
+    np.random.seed(seed)
+    random.seed(seed)
+    pl = Player(cfg, training=True, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak))
+    C = S * S
+    out = dict(seed=np.asarray(seed), salt=np.asarray(salt), peak=np.asarray(peak), episodes=np.asarray(episodes))
+    out.update(cfg_arrays(cfg))
+    for e in range(episodes):
+        rec = pl.run()
+        # main.py:85-93 gen_data result code
+        value = rec[-1][-2]
+        if value == 0.0:
+            result = refutils.DRAW
+        elif len(rec) % 2 == 1:
+            result = refutils.BLACK_WIN
+        else:
+            result = refutils.WHITE_WIN
+        out[f"ep{e}_states"] = np.array([r[0] for r in rec])
+        out[f"ep{e}_policies"] = np.array([r[1].reshape(-1) for r in rec], np.float32)
+        out[f"ep{e}_lasts"] = np.array([-1 if r[2] is None else r[2][0] * S + r[2][1] for r in rec], np.int32)
+        out[f"ep{e}_values"] = np.array([r[3] for r in rec], np.float64)
+        out[f"ep{e}_weights"] = np.array([r[4] for r in rec], np.float32)
+        out[f"ep{e}_result"] = np.asarray(result)
+        assert all(isinstance(r[4], np.float32) for r in rec) and all(isinstance(r[3], float) for r in rec)
+        assert len(pl.tree) == 0
+        print(os.path.basename(path), "episode", e, "T", len(rec), "result", result)
+    out["np_next"] = np.asarray(int(np.random.randint(0, 2 ** 32, dtype=np.uint64)))
+    out["py_next"] = np.asarray(random.getrandbits(32))
+    np.savez_compressed(path, **out)
+
+
+def main():
+    gen_rules(os.path.join(HERE, "rules.npz"))
+    G = lambda name: os.path.join(HERE, name)  # noqa: E731
+    # training mode, forced root visits not exhausted (sims < 2L) and exhausted (sims > 2L)
+    gen_mcts(G("mcts_s11_train_a.npz"), 11, 5, 60, 80, True, 0, 1234, 0, 12)
+    gen_mcts(G("mcts_s11_train_b.npz"), 11, 5, 300, 400, True, 5, 99, 8192, 3)
+    gen_mcts(G("mcts_s6_train.npz"), 6, 4, 120, 160, True, 3, 1237, 16384, 40)
+    gen_mcts(G("mcts_s7_train.npz"), 7, 4, 50, 70, True, 1, 1235, 4096, 40)
+    # eval mode (self_play.py loop: training=False, tree shared, never reset)
+    gen_mcts(G("mcts_s11_eval.npz"), 11, 5, 80, 100, False, 2, 1236, 8192, 14)
+    gen_mcts(G("mcts_s6_eval.npz"), 6, 4, 100, 120, False, 4, 77, 16384, 40)
+    # arena mode (choose_best_player.py: training=False, random_a=True)
+    gen_mcts(G("mcts_s7_arena.npz"), 7, 4, 60, 80, False, 6, 78, 4096, 40, random_a=True)
+    # 15x15
+    gen_mcts(G("mcts_s15_train.npz"), 15, 5, 40, 60, True, 8, 5, 8192, 4)
+    # whole episodes through Player.run (tree reset, value signs, weights, result code)
+    gen_run(G("run_s6.npz"), 6, 4, 60, 80, 11, 4242, 16384, 3)
+    gen_run(G("run_s7.npz"), 7, 4, 40, 60, 12, 4243, 4096, 2)
+
+
+if __name__ == "__main__":
+    main()
