@@ -1,0 +1,47 @@
+"""In-tree build of the HIP engine for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m alphafive_amd.build            # builds alphafive_amd/_lib/*.so
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+LIBDIR = os.path.join(PKG, "_lib")
+ARCH = "gfx950"
+
+HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(REPO, "include")]
+
+# name -> (sources, extra flags).  -ffp-contract=off: the tree engine's arithmetic must be
+# exactly as written; the net kernels are free to contract (fp32 MFMA is an fma chain).
+TARGETS = {
+    "libaf_hip.so": (["csrc/af_engine.hip"], ["-ffp-contract=off"]),
+}
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    deps = list(srcs) + [os.path.join(REPO, "include", f) for f in os.listdir(os.path.join(REPO, "include"))]
+    return any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build_all(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    built = []
+    for name, (srcs, extra) in TARGETS.items():
+        out = os.path.join(LIBDIR, name)
+        srcs = [os.path.join(PKG, s) for s in srcs]
+        if force or _stale(out, srcs):
+            cmd = [hipcc] + HIPCC_FLAGS + extra + ["-o", out] + srcs
+            if verbose:
+                print("[alphafive_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        built.append(out)
+    return built
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,1014 @@
+// af_engine.hip — MI355X (gfx950) self-play engine: thousands of concurrent Gomoku
+// MCTS games resident in HBM, one 64-lane wavefront per game.
+//
+// What the reference does per simulation in Python (genData/player.py:204-228
+// MCTS_search, :230 select_action_q_and_u, :186 evaluate_and_expand, :166
+// update_tree, :84 calc_policy; utils.py:199 is_game_over, :238 get_legal_actions,
+// :256 board_to_inputs, :275 step) is done here by ONE kernel launch per tick for
+// all games: the wave that owns a game consumes the evaluation of the leaf it
+// parked on, then keeps descending / backing up / finishing moves until it parks
+// on the next unseen position, whose input planes it writes for the batched net.
+//
+// Layout (SoA, one slice per game, everything stays resident between ticks):
+//   position key   2*KW u64 : "mine" bitboard, "theirs" bitboard (bit c = cell i*S+j)
+//   node stats     dense by cell, CP = 64*KW slots per node: N (int32, bit31 = "W is
+//                  fp32-typed", SURVEY §8a rule 2), W (fp32 running sum), P (fp32 prior)
+//                  lane l owns cells l, l+64, ...  -> every stats access is one
+//                  coalesced 256-byte row per array
+//   store          per-game open-addressing table (u32 slot = node index + 1) over an
+//                  exact-key node pool; unreachable nodes (stones not a superset of
+//                  the root's) are compacted away under capacity pressure
+// Arithmetic follows SURVEY §8a to the bit: fp32 sequential prior sum, fp32 W, fp64
+// PUCT score rounded to fp32, ties on the fp32 score.  Compiled -ffp-contract=off.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "af_engine.h"
+#include "af_noise.h"
+
+typedef unsigned long long u64;
+
+enum { PH_IDLE = 0, PH_MOVE_START = 1, PH_SEARCH = 2, PH_MOVE_DONE = 3, PH_ERROR = 4 };
+enum { CT_SIMS = 0, CT_SELECTS, CT_EXPANDS, CT_TERMINALS, CT_PLIES, CT_EPISODES, CT_LSUM, CT_RESERVED, CT_N };
+
+struct EngineParams {
+    int G, S, C, goal, sims, upper, training, mode, node_cap, max_ply;
+    uint32_t hash_mask;
+    double init_temp, tau_decay, tau_decay_r, alpha, c_puct;
+    float c_puct32;
+    uint32_t k0, seed_hi, first_game_id;
+    u64 colmask[4], boardmask[4];
+    // per-game state
+    int32_t *phase, *pending, *sims_left, *ply, *root_last, *nodes, *depth, *leaf_last, *leaf_slot, *status, *random_a;
+    int32_t *action, *has_policy, *visits;
+    float* policy;
+    u64 *root, *leaf;
+    double* tau;
+    uint32_t *episode, *sel, *plyctr;
+    int32_t *path_node, *path_cell;
+    // transposition store
+    uint32_t* hash;
+    u64* node_key;
+    int32_t* node_sum;
+    int32_t* edge_n;
+    float *edge_w, *edge_p;
+    // finished-episode double buffers
+    uint32_t *ep_seq, *ep_popped;
+    int32_t* ep_len;
+    float* ep_final;
+    u64* rec_key;
+    float* rec_policy;
+    int32_t *rec_visits, *rec_last, *rec_action;
+    u64* counters;
+};
+
+// ----------------------------------------------------------------------------------------------
+// device helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rfl32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ int rfli(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ u64 rfl64(u64 x) {
+    return ((u64)rfl32((uint32_t)(x >> 32)) << 32) | (u64)rfl32((uint32_t)x);
+}
+__device__ __forceinline__ float rflf(float x) { return __int_as_float(rfli(__float_as_int(x))); }
+
+template <int KW>
+__device__ __forceinline__ void bb_shr(const u64* a, int d, u64* o) {   // 0 < d < 64
+#pragma unroll
+    for (int k = 0; k < KW; ++k) o[k] = (a[k] >> d) | (k + 1 < KW ? (a[k + 1] << (64 - d)) : 0ull);
+}
+template <int KW>
+__device__ __forceinline__ void bb_shl(const u64* a, int d, u64* o) {
+#pragma unroll
+    for (int k = KW - 1; k >= 0; --k) o[k] = (a[k] << d) | (k > 0 ? (a[k - 1] >> (64 - d)) : 0ull);
+}
+template <int KW>
+__device__ __forceinline__ int bb_first(const u64* a) {   // lowest set bit index or -1
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+        if (a[k]) return 64 * k + __builtin_ctzll(a[k]);
+    return -1;
+}
+template <int KW>
+__device__ __forceinline__ int bb_count(const u64* a) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) n += __popcll(a[k]);
+    return n;
+}
+template <int KW>
+__device__ __forceinline__ int bb_select(const u64* a, int r) {   // index of the r-th set bit (ascending)
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        int pc = __popcll(a[k]);
+        if (r < pc) {
+            u64 x = a[k];
+            for (int i = 0; i < r; ++i) x &= x - 1;
+            return 64 * k + __builtin_ctzll(x);
+        }
+        r -= pc;
+    }
+    return -1;
+}
+template <int KW>
+__device__ __forceinline__ bool bb_test(const u64* a, int c) { return (a[c >> 6] >> (c & 63)) & 1ull; }
+
+// run masks: bit c set iff `goal` consecutive stones start at c along the direction
+template <int KW, bool LEFT>
+__device__ __forceinline__ void run_mask(const u64* b, int d, int goal, const u64* valid, u64* out) {
+    u64 cur[KW], nxt[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) { cur[k] = b[k]; out[k] = b[k]; }
+    for (int t = 1; t < goal; ++t) {
+        if (LEFT) bb_shl<KW>(cur, d, nxt); else bb_shr<KW>(cur, d, nxt);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) { cur[k] = nxt[k]; out[k] &= nxt[k]; }
+    }
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) out[k] &= valid[k];
+    }
+}
+
+// utils.py:199-235 is_game_over on bitboards.  Scan order of the reference (cell-major,
+// then down / right / diag-down-right / diag-up-right) decides when both colours have a line.
+template <int KW>
+__device__ int terminal_test(const EngineParams& P, const u64* mine, const u64* theirs, float* value) {
+    int best_key = 0x7fffffff;
+    float best_v = 0.0f;
+    const int S = P.S;
+#pragma unroll
+    for (int dir = 0; dir < 4; ++dir) {
+        u64 wm[KW], wt[KW], any[KW];
+        const int d = dir == 0 ? S : (dir == 1 ? 1 : (dir == 2 ? S + 1 : S - 1));
+        const u64* valid = dir == 0 ? nullptr : P.colmask;
+        if (dir == 3) {
+            run_mask<KW, true>(mine, d, P.goal, valid, wm);
+            run_mask<KW, true>(theirs, d, P.goal, valid, wt);
+        } else {
+            run_mask<KW, false>(mine, d, P.goal, valid, wm);
+            run_mask<KW, false>(theirs, d, P.goal, valid, wt);
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) any[k] = wm[k] | wt[k];
+        const int f = bb_first<KW>(any);
+        if (f >= 0) {
+            const int key = f * 4 + dir;
+            if (key < best_key) { best_key = key; best_v = bb_test<KW>(wm, f) ? 1.0f : -1.0f; }
+        }
+    }
+    if (best_key != 0x7fffffff) { *value = best_v; return 1; }
+    bool full = true;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) full = full && ((mine[k] | theirs[k]) == P.boardmask[k]);
+    *value = 0.0f;
+    return full ? 1 : 0;
+}
+
+template <int KW>
+__device__ __forceinline__ uint32_t key_hash(const u64* mine, const u64* theirs) {
+    u64 h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        h = (h ^ mine[k]) * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+        h = (h ^ theirs[k]) * 0xc4ceb9fe1a85ec53ull;
+        h ^= h >> 32;
+    }
+    return (uint32_t)h;
+}
+
+// Wave-cooperative exact-key lookup: 64 consecutive slots per round.
+// Returns node index or -1; *slot_out = slot where the key would be inserted.
+template <int KW>
+__device__ int tree_lookup(const EngineParams& P, int g, const u64* mine, const u64* theirs, int lane, uint32_t* slot_out) {
+    const uint32_t* slots = P.hash + (size_t)g * (P.hash_mask + 1);
+    const u64* keys = P.node_key + (size_t)g * P.node_cap * (2 * KW);
+    const uint32_t h = key_hash<KW>(mine, theirs);
+    for (uint32_t round = 0; round <= P.hash_mask / 64 + 1; ++round) {
+        const uint32_t s = (h + round * 64 + lane) & P.hash_mask;
+        const uint32_t v = slots[s];
+        const u64 empties = __ballot(v == 0);
+        const int first_empty = empties ? __builtin_ctzll(empties) : 64;
+        bool match = false;
+        if (v != 0 && lane < first_empty) {
+            const u64* kk = keys + (size_t)(v - 1) * (2 * KW);
+            match = true;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) match = match && kk[k] == mine[k] && kk[KW + k] == theirs[k];
+        }
+        const u64 mm = __ballot(match);
+        if (mm) {
+            const int src = __builtin_ctzll(mm);
+            return (int)__shfl((int)v, src) - 1;
+        }
+        if (first_empty < 64) {
+            *slot_out = (h + round * 64 + first_empty) & P.hash_mask;
+            return -1;
+        }
+    }
+    *slot_out = 0xffffffffu;
+    return -1;
+}
+
+// numpy float32 add.reduce restated (pairwise, 8 accumulators) over an LDS array
+__device__ float pairwise_block(const float* a, int n) {
+    if (n < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < n; ++i) r = r + a[i];
+        return r;
+    }
+    float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 = r0 + a[i]; r1 = r1 + a[i + 1]; r2 = r2 + a[i + 2]; r3 = r3 + a[i + 3];
+        r4 = r4 + a[i + 4]; r5 = r5 + a[i + 5]; r6 = r6 + a[i + 6]; r7 = r7 + a[i + 7];
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+}
+__device__ float pairwise_sum(const float* a, int n) {   // n <= 256
+    if (n <= 128) return pairwise_block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_block(a, n2) + pairwise_block(a + n2, n - n2);
+}
+
+// ----------------------------------------------------------------------------------------------
+// the tick kernel: one wavefront (= one workgroup) per game
+// ----------------------------------------------------------------------------------------------
+template <int KW>
+__global__ __launch_bounds__(64) void af_tick_kernel(EngineParams P, const float* __restrict__ policy_in,
+                                                     const float* __restrict__ value_in, float* __restrict__ planes_out) {
+    constexpr int CP = 64 * KW;
+    __shared__ float s_pv[CP];
+    __shared__ double s_cdf[CP];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int C = P.C, NCAP = P.node_cap;
+
+    int phase = rfli(P.phase[g]);
+    if (phase == PH_IDLE || phase == PH_MOVE_DONE || phase == PH_ERROR) return;
+
+    // ---- load game state (wave-uniform) ----
+    u64 root_m[KW], root_t[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        root_m[k] = rfl64(P.root[(size_t)g * 2 * KW + k]);
+        root_t[k] = rfl64(P.root[(size_t)g * 2 * KW + KW + k]);
+    }
+    int root_last = rfli(P.root_last[g]);
+    int sims_left = rfli(P.sims_left[g]);
+    int ply = rfli(P.ply[g]);
+    int nodes = rfli(P.nodes[g]);
+    double tau = P.tau[g];
+    uint32_t episode = rfl32(P.episode[g]);
+    uint32_t sel = rfl32(P.sel[g]);
+    uint32_t plyctr = rfl32(P.plyctr[g]);
+    const int random_a = rfli(P.random_a[g]);
+    const uint32_t k0 = P.k0, k1 = P.seed_hi + (P.first_game_id + (uint32_t)g);
+    u64 ct[CT_N];
+#pragma unroll
+    for (int i = 0; i < CT_N; ++i) ct[i] = 0;
+    int err = 0;
+
+    u64* const nkeys = P.node_key + (size_t)g * NCAP * (2 * KW);
+    int32_t* const nsum = P.node_sum + (size_t)g * NCAP;
+    int32_t* const en = P.edge_n + (size_t)g * NCAP * CP;
+    float* const ew = P.edge_w + (size_t)g * NCAP * CP;
+    float* const ep = P.edge_p + (size_t)g * NCAP * CP;
+    uint32_t* const slots = P.hash + (size_t)g * (P.hash_mask + 1);
+    int32_t* const pnode = P.path_node + (size_t)g * CP;
+    int32_t* const pcell = P.path_cell + (size_t)g * CP;
+
+    // backup along the stored path: player.py:166-184 update_tree.  Path element d receives
+    // v * (-1)^(depth-d); is_f32 marks net values (np.float32) vs terminal values (python float).
+    auto backup = [&](int depth, float v, int is_f32) {
+        for (int d = lane; d < depth; d += 64) {
+            const size_t off = (size_t)pnode[d] * CP + pcell[d];
+            const float vv = ((depth - d) & 1) ? -v : v;
+            const int32_t raw = en[off];
+            en[off] = (raw + 1) | (is_f32 ? (int32_t)0x80000000 : 0);
+            ew[off] = ew[off] + vv;
+        }
+        __syncthreads();
+    };
+
+    // ---- 1. consume the evaluation of the parked leaf: player.py:186-202 + :166 ----
+    if (rfli(P.pending[g])) {
+        u64 lm[KW], lt[KW], legal[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            lm[k] = rfl64(P.leaf[(size_t)g * 2 * KW + k]);
+            lt[k] = rfl64(P.leaf[(size_t)g * 2 * KW + KW + k]);
+            legal[k] = ~(lm[k] | lt[k]) & P.boardmask[k];
+        }
+        const int depth = rfli(P.depth[g]);
+        const uint32_t slot = rfl32((uint32_t)P.leaf_slot[g]);
+        float pk[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int c = lane + 64 * k;
+            pk[k] = ((legal[k] >> lane) & 1ull) ? policy_in[(size_t)g * C + c] : 0.0f;
+        }
+        // all_p: left-to-right fp32 sum in row-major legal order (SURVEY §8a rule 1)
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk[k]), l));
+        }
+        if (!((double)s >= 1e-5)) s = (float)1e-5;
+        if (nodes >= NCAP || slot == 0xffffffffu) {
+            err = AF_ERR_NODE_CAP;
+        } else {
+            const int idx = nodes++;
+            if (lane < 2 * KW) nkeys[(size_t)idx * 2 * KW + lane] = lane < KW ? lm[lane] : lt[lane - KW];
+            if (lane == 0) { nsum[idx] = 0; slots[slot] = (uint32_t)idx + 1u; }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const size_t off = (size_t)idx * CP + lane + 64 * k;
+                en[off] = 0;
+                ew[off] = 0.0f;
+                ep[off] = ((legal[k] >> lane) & 1ull) ? pk[k] / s : 0.0f;
+            }
+            __syncthreads();
+            backup(depth, rflf(value_in[g]), 1);
+            ct[CT_EXPANDS]++;
+        }
+        ct[CT_SIMS]++;
+        sims_left--;
+    }
+
+    int status = AF_STATUS_IDLE;
+    bool parked = false;
+
+    // ---- 2. advance until the game parks ----
+    while (!parked && !err) {
+        if (phase == PH_MOVE_START) {
+            // capacity pressure: drop nodes whose stones are not a superset of the root's (they can
+            // never be reached again: play only adds stones; the reference never revisits them either)
+            if (nodes + P.sims + 2 > NCAP && nodes > 0) {
+                const int rc = bb_count<KW>(root_m) + bb_count<KW>(root_t);
+                int dst = 0;
+                for (int i = 0; i < nodes; ++i) {
+                    u64 nm[KW], nt[KW];
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) { nm[k] = rfl64(nkeys[(size_t)i * 2 * KW + k]); nt[k] = rfl64(nkeys[(size_t)i * 2 * KW + KW + k]); }
+                    const int nc = bb_count<KW>(nm) + bb_count<KW>(nt);
+                    bool keep = true;
+                    // colour of "mine" is fixed by stone-count parity
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) {
+                        const u64 a = ((nc ^ rc) & 1) ? nt[k] : nm[k];
+                        const u64 b = ((nc ^ rc) & 1) ? nm[k] : nt[k];
+                        keep = keep && ((a & root_m[k]) == root_m[k]) && ((b & root_t[k]) == root_t[k]);
+                    }
+                    if (keep) {
+                        if (dst != i) {
+                            if (lane < 2 * KW) nkeys[(size_t)dst * 2 * KW + lane] = lane < KW ? nm[lane] : nt[lane - KW];
+                            if (lane == 0) nsum[dst] = nsum[i];
+#pragma unroll
+                            for (int k = 0; k < KW; ++k) {
+                                const size_t so = (size_t)i * CP + lane + 64 * k, d_ = (size_t)dst * CP + lane + 64 * k;
+                                en[d_] = en[so]; ew[d_] = ew[so]; ep[d_] = ep[so];
+                            }
+                        }
+                        ++dst;
+                    }
+                }
+                nodes = dst;
+                for (uint32_t s_ = lane; s_ <= P.hash_mask; s_ += 64) slots[s_] = 0;
+                __syncthreads();
+                for (int i = lane; i < nodes; i += 64) {
+                    u64 nm[KW], nt[KW];
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) { nm[k] = nkeys[(size_t)i * 2 * KW + k]; nt[k] = nkeys[(size_t)i * 2 * KW + KW + k]; }
+                    uint32_t h = key_hash<KW>(nm, nt);
+                    for (;;) {
+                        h &= P.hash_mask;
+                        if (atomicCAS(&slots[h], 0u, (uint32_t)i + 1u) == 0u) break;
+                        ++h;
+                    }
+                }
+                __syncthreads();
+            }
+            uint32_t slot;
+            const int ridx = tree_lookup<KW>(P, g, root_m, root_t, lane, &slot);
+            int num = P.sims;                                           // player.py:140-143
+            if (ridx >= 0) { const int rem = P.upper - rfli(nsum[ridx]); num = rem < num ? rem : num; }
+            sims_left = num;
+            phase = PH_SEARCH;
+        }
+
+        if (sims_left <= 0) {
+            // ------------- player.py:84-126 calc_policy -------------
+            uint32_t slot;
+            const int ridx = tree_lookup<KW>(P, g, root_m, root_t, lane, &slot);
+            if (ridx < 0) { err = AF_ERR_NO_ROOT; break; }
+            u64 legal[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) legal[k] = ~(root_m[k] | root_t[k]) & P.boardmask[k];
+            const int L = bb_count<KW>(legal);
+            int nv[KW];
+            int most = -1;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const bool lg = (legal[k] >> lane) & 1ull;
+                nv[k] = lg ? (en[(size_t)ridx * CP + lane + 64 * k] & 0x7fffffff) : -1;
+                most = nv[k] > most ? nv[k] : most;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(most, off); most = o > most ? o : most; }
+            u64 best[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) best[k] = __ballot(nv[k] == most && nv[k] >= 0);
+            const int nb = bb_count<KW>(best);
+            const uint32_t plyc = plyctr++;
+            const int bi = (int)af_pick((uint32_t)nb, plyc, episode, AF_STREAM_BEST, k0, k1);   // :102
+            const int best_cell = bb_select<KW>(best, bi);
+            int action = best_cell, has_policy = 1;
+            float pol[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) pol[k] = 0.0f;
+            ct[CT_PLIES]++;
+            if (!P.training && !random_a) {
+                has_policy = 0;                                                                  // :106-107
+            } else {
+                tau = tau * (random_a ? P.tau_decay_r : P.tau_decay);                            // :108-111
+                if (tau <= 0.01) {                                                               // :112-115
+                    const float u = (float)(1.0 / (double)nb);
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) pol[k] = ((best[k] >> lane) & 1ull) ? u : 0.0f;
+                } else {
+                    const float mx = (float)most;
+                    const float inv_tau = (float)(1.0 / tau);
+                    int e_idx[KW];
+                    int base = 0;
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) {
+                        const bool lg = (legal[k] >> lane) & 1ull;
+                        e_idx[k] = base + __popcll(legal[k] & ((1ull << lane) - 1ull));
+                        base += __popcll(legal[k]);
+                        if (lg) {
+                            float x = (float)nv[k] / mx;                                         // :116
+                            x = af_powf(x, inv_tau);                                             // :117
+                            pol[k] = x;
+                            s_pv[e_idx[k]] = x;
+                        }
+                    }
+                    __syncthreads();
+                    const float sum = pairwise_sum(s_pv, L);                                     // :118 np.sum
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) {
+                        if ((legal[k] >> lane) & 1ull) { pol[k] = pol[k] / sum; s_pv[e_idx[k]] = pol[k]; }
+                    }
+                    __syncthreads();
+                    // :125 np.random.choice(L, p): fp64 cumsum, / last, searchsorted(side='right')
+                    if (lane == 0) {
+                        double acc = 0.0;
+                        for (int e = 0; e < L; ++e) { acc = acc + (double)s_pv[e]; s_cdf[e] = acc; }
+                    }
+                    __syncthreads();
+                    const double last = s_cdf[L - 1];
+                    const double u = af_uniform(plyc, episode, AF_STREAM_MOVE, k0, k1);
+                    int cnt = 0;
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) {
+                        const bool lg = (legal[k] >> lane) & 1ull;
+                        const bool le = lg && (s_cdf[e_idx[k]] / last <= u);
+                        cnt += __popcll(__ballot(le));
+                    }
+                    __syncthreads();
+                    if (cnt >= L) cnt = L - 1;
+                    action = bb_select<KW>(legal, cnt);
+                }
+            }
+            // publish the move result
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                P.policy[(size_t)g * CP + lane + 64 * k] = pol[k];
+                P.visits[(size_t)g * CP + lane + 64 * k] = nv[k] < 0 ? 0 : nv[k];
+            }
+            if (lane == 0) { P.action[g] = action; P.has_policy[g] = has_policy; }
+
+            if (P.mode == AF_MODE_EXTERNAL) {
+                phase = PH_MOVE_DONE;
+                status = AF_STATUS_MOVE_DONE;
+                parked = true;
+                break;
+            }
+            // ------------- player.py:53-82 run: record, step, game over? -------------
+            if (ply >= P.max_ply) { err = AF_ERR_STATE; break; }
+            const uint32_t seq = rfl32(P.ep_seq[g]);
+            const size_t rslot = ((size_t)g * 2 + (seq & 1u)) * P.max_ply + ply;
+            if (lane < 2 * KW) P.rec_key[rslot * 2 * KW + lane] = lane < KW ? root_m[lane] : root_t[lane - KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int c = lane + 64 * k;
+                if (c < C) { P.rec_policy[rslot * C + c] = pol[k]; P.rec_visits[rslot * C + c] = nv[k] < 0 ? 0 : nv[k]; }
+            }
+            if (lane == 0) { P.rec_last[rslot] = root_last; P.rec_action[rslot] = action; }
+            // utils.py:275 step: place my stone, flip perspective
+            {
+                u64 nm[KW], nt[KW];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) { nm[k] = root_t[k]; nt[k] = root_m[k]; }
+                nt[action >> 6] |= 1ull << (action & 63);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) { root_m[k] = nm[k]; root_t[k] = nt[k]; }
+            }
+            root_last = action;
+            ++ply;
+            float fv;
+            if (terminal_test<KW>(P, root_m, root_t, &fv)) {
+                // episode finished: publish, then Player.reset() (:73) and start the next game
+                if (seq - rfl32(P.ep_popped[g]) >= 2u) { err = AF_ERR_EP_OVERRUN; break; }
+                if (lane == 0) {
+                    P.ep_len[(size_t)g * 2 + (seq & 1u)] = ply;
+                    P.ep_final[(size_t)g * 2 + (seq & 1u)] = fv;
+                    P.ep_seq[g] = seq + 1u;
+                }
+                ct[CT_EPISODES]++;
+                for (uint32_t s_ = lane; s_ <= P.hash_mask; s_ += 64) slots[s_] = 0;
+                __syncthreads();
+                nodes = 0;
+#pragma unroll
+                for (int k = 0; k < KW; ++k) { root_m[k] = 0; root_t[k] = 0; }
+                root_last = -1;
+                ply = 0;
+                tau = P.init_temp;
+                episode += 1; sel = 0; plyctr = 0;
+            }
+            phase = PH_MOVE_START;
+            continue;
+        }
+
+        // ------------- one simulation: player.py:204-228 MCTS_search -------------
+        u64 cm[KW], ctb[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) { cm[k] = root_m[k]; ctb[k] = root_t[k]; }
+        int last = root_last, depth = 0;
+        for (;;) {
+            float tv;
+            if (terminal_test<KW>(P, cm, ctb, &tv)) {                       // :213-217
+                backup(depth, tv, 0);
+                ct[CT_TERMINALS]++; ct[CT_SIMS]++;
+                sims_left--;
+                break;
+            }
+            uint32_t slot;
+            const int idx = tree_lookup<KW>(P, g, cm, ctb, lane, &slot);
+            if (idx < 0) {                                                  // :218 unseen -> park for the net
+                if (lane < 2 * KW) P.leaf[(size_t)g * 2 * KW + lane] = lane < KW ? cm[lane] : ctb[lane - KW];
+                if (lane == 0) { P.depth[g] = depth; P.leaf_last[g] = last; P.leaf_slot[g] = (int32_t)slot; }
+                // utils.py:256 board_to_inputs -> float32[3][S][S]
+                float* out = planes_out + (size_t)g * 3 * C;
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int c = lane + 64 * k;
+                    if (c < C) {
+                        out[c] = ((cm[k] >> lane) & 1ull) ? 1.0f : 0.0f;
+                        out[C + c] = ((ctb[k] >> lane) & 1ull) ? 1.0f : 0.0f;
+                        out[2 * C + c] = c == last ? 1.0f : 0.0f;
+                    }
+                }
+                status = AF_STATUS_NEED_EVAL;
+                parked = true;
+                break;
+            }
+            // ------------- player.py:230-279 select_action_q_and_u -------------
+            const bool is_root = depth == 0;
+            u64 legal[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) legal[k] = ~(cm[k] | ctb[k]) & P.boardmask[k];
+            const int sum_n = rfli(nsum[idx]) + 1;                          // :237
+            if (lane == 0) nsum[idx] = sum_n;
+            const uint32_t sel_id = sel++;
+            int nn[KW];
+            float ww[KW], pp[KW];
+            bool ff[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const size_t off = (size_t)idx * CP + lane + 64 * k;
+                const int32_t raw = en[off];
+                nn[k] = raw & 0x7fffffff;
+                ff[k] = raw < 0;
+                ww[k] = ew[off];
+                pp[k] = ep[off];
+            }
+            double dd[KW];
+            if (P.training) {
+                // Dirichlet(alpha) noise, tier-B generator (af_noise.h); summation order = lane partials
+                // then xor butterfly, identical to oracle afo_noise_philox_dirichlet
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const bool lg = (legal[k] >> lane) & 1ull;
+                    dd[k] = lg ? af_gamma_lt1(P.alpha, sel_id, episode, (uint32_t)(lane + 64 * k), k0, k1) : 0.0;
+                    acc = k == 0 ? dd[0] : acc + dd[k];
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+                const double inv = 1.0 / acc;
+#pragma unroll
+                for (int k = 0; k < KW; ++k) dd[k] = dd[k] * inv;
+            }
+            const double sq = sqrt((double)(sum_n + 1));
+            float sc[KW];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const bool lg = (legal[k] >> lane) & 1ull;
+                double q64;                                                 // SURVEY §8a rule 2
+                if (nn[k] == 0) q64 = 0.0;
+                else if (ff[k]) q64 = (double)(ww[k] / (float)nn[k]);
+                else q64 = (double)ww[k] / (double)nn[k];
+                double t;
+                if (P.training) {                                           // rule 3
+                    double p_;
+                    if (is_root) p_ = (double)(0.75f * pp[k]) + 0.25 * dd[k];
+                    else p_ = (double)(0.9f * pp[k]) + 0.1 * dd[k];
+                    t = ((P.c_puct * p_) * sq) / (double)(1 + nn[k]);
+                } else {
+                    t = ((double)(P.c_puct32 * pp[k]) * sq) / (double)(1 + nn[k]);
+                }
+                sc[k] = lg ? (float)(q64 + t) : -3.0e38f;
+                mx = sc[k] > mx ? sc[k] : mx;
+            }
+            int cell = -1;
+            if (is_root && P.training) {                                    // :264-276 forced root visits
+                u64 cand[KW];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) cand[k] = __ballot(((legal[k] >> lane) & 1ull) && nn[k] == 0);
+                int m = bb_count<KW>(cand);
+                if (m == 0) {
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) cand[k] = __ballot(((legal[k] >> lane) & 1ull) && nn[k] == 1);
+                    m = bb_count<KW>(cand);
+                }
+                if (m > 0) cell = bb_select<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1));
+            }
+            if (cell < 0) {                                                 // :277-279 argmax with uniform tie-break
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+                u64 cand[KW];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) cand[k] = __ballot(((legal[k] >> lane) & 1ull) && sc[k] == mx);
+                const int m = bb_count<KW>(cand);
+                cell = bb_select<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1));
+            }
+            cell = rfli(cell);
+            ct[CT_SELECTS]++;
+            ct[CT_LSUM] += (u64)bb_count<KW>(legal);
+            if (lane == 0) { pnode[depth] = idx; pcell[depth] = cell; }
+            ++depth;
+            // utils.py:275 step
+            {
+                u64 nm[KW], nt[KW];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) { nm[k] = ctb[k]; nt[k] = cm[k]; }
+                nt[cell >> 6] |= 1ull << (cell & 63);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) { cm[k] = nm[k]; ctb[k] = nt[k]; }
+            }
+            last = cell;
+            __syncthreads();
+        }
+    }
+
+    // ---- 3. store state ----
+    if (err) { phase = PH_ERROR; status = err; }
+    if (lane < 2 * KW) P.root[(size_t)g * 2 * KW + lane] = lane < KW ? root_m[lane] : root_t[lane - KW];
+    if (lane == 0) {
+        P.phase[g] = phase;
+        P.pending[g] = status == AF_STATUS_NEED_EVAL ? 1 : 0;
+        P.root_last[g] = root_last;
+        P.sims_left[g] = sims_left;
+        P.ply[g] = ply;
+        P.nodes[g] = nodes;
+        P.tau[g] = tau;
+        P.episode[g] = episode;
+        P.sel[g] = sel;
+        P.plyctr[g] = plyctr;
+        P.status[g] = status;
+        for (int i = 0; i < CT_N; ++i) P.counters[(size_t)g * CT_N + i] += ct[i];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------
+struct af_engine {
+    EngineParams P;
+    int device;
+    int KW;
+    std::vector<void*> allocs;
+    std::vector<int32_t> h_i32;
+    std::vector<uint32_t> h_seq, h_popped;
+    std::vector<u64> h_ct;
+};
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[af_engine] %s failed: %s\n", #x, hipGetErrorString(e_)); return AF_ERR_HIP; } } while (0)
+
+template <typename T>
+static int dalloc(af_engine* e, T** p, size_t n) {
+    void* q = nullptr;
+    HIP_OK(hipMalloc(&q, n * sizeof(T)));
+    HIP_OK(hipMemset(q, 0, n * sizeof(T)));
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return AF_OK;
+}
+
+extern "C" {
+
+int af_abi_version(void) { return AF_ABI_VERSION; }
+
+const char* af_strerror(int code) {
+    switch (code) {
+        case AF_OK: return "ok";
+        case AF_ERR_ARG: return "bad argument";
+        case AF_ERR_HIP: return "HIP runtime error";
+        case AF_ERR_NODE_CAP: return "transposition store full (raise node_cap)";
+        case AF_ERR_NO_ROOT: return "get_action on a finished position";
+        case AF_ERR_EP_OVERRUN: return "finished episodes not popped in time";
+        case AF_ERR_STATE: return "engine state error";
+        default: return "unknown error";
+    }
+}
+
+int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, int32_t mode, int32_t training,
+                     uint64_t seed, uint32_t first_game_id, int32_t node_cap, af_engine** out) {
+    if (!cfg || !out || num_games < 1) return AF_ERR_ARG;
+    const int S = cfg->board_size, C = S * S;
+    if (S < 2 || C > 256 || cfg->goal < 2 || cfg->goal > S || cfg->simulation_per_step < 1) return AF_ERR_ARG;
+    if (mode != AF_MODE_SELFPLAY && mode != AF_MODE_EXTERNAL) return AF_ERR_ARG;
+    HIP_OK(hipSetDevice(device));
+    af_engine* e = new af_engine();
+    e->device = device;
+    e->KW = C <= 128 ? 2 : 4;
+    const int KW = e->KW, CP = 64 * KW;
+    EngineParams& P = e->P;
+    memset(&P, 0, sizeof(P));
+    P.G = num_games; P.S = S; P.C = C; P.goal = cfg->goal;
+    P.sims = cfg->simulation_per_step; P.upper = cfg->upper_simulation_per_step;
+    P.training = training ? 1 : 0; P.mode = mode; P.max_ply = C;
+    if (node_cap <= 0) node_cap = mode == AF_MODE_SELFPLAY ? 4 * P.sims + 64 : 32768;
+    if (node_cap < P.sims + 8) node_cap = P.sims + 8;
+    P.node_cap = node_cap;
+    uint32_t hcap = 64;
+    while (hcap < 2u * (uint32_t)node_cap) hcap <<= 1;
+    P.hash_mask = hcap - 1;
+    P.init_temp = cfg->init_temp; P.tau_decay = cfg->tau_decay_rate; P.tau_decay_r = cfg->tau_decay_rate_r;
+    P.alpha = cfg->dirichlet_alpha; P.c_puct = cfg->c_puct; P.c_puct32 = (float)cfg->c_puct;
+    P.k0 = af_key0(seed); P.seed_hi = (uint32_t)(seed >> 32); P.first_game_id = first_game_id;
+    for (int c = 0; c < C; ++c) {
+        P.boardmask[c >> 6] |= 1ull << (c & 63);
+        if (c % S <= S - cfg->goal) P.colmask[c >> 6] |= 1ull << (c & 63);
+    }
+    const size_t G = num_games;
+    int rc = AF_OK;
+#define A(p, n) if (rc == AF_OK) rc = dalloc(e, &P.p, (n))
+    A(phase, G); A(pending, G); A(sims_left, G); A(ply, G); A(root_last, G); A(nodes, G); A(depth, G);
+    A(leaf_last, G); A(leaf_slot, G); A(status, G); A(random_a, G); A(action, G); A(has_policy, G);
+    A(visits, G * CP); A(policy, G * CP); A(root, G * 2 * KW); A(leaf, G * 2 * KW); A(tau, G);
+    A(episode, G); A(sel, G); A(plyctr, G); A(path_node, G * CP); A(path_cell, G * CP);
+    A(hash, G * hcap); A(node_key, G * node_cap * 2 * KW); A(node_sum, G * node_cap);
+    A(edge_n, G * node_cap * CP); A(edge_w, G * node_cap * CP); A(edge_p, G * node_cap * CP);
+    A(ep_seq, G); A(ep_popped, G); A(counters, G * CT_N);
+    if (mode == AF_MODE_SELFPLAY) {
+        const size_t R = G * 2 * P.max_ply;
+        A(ep_len, G * 2); A(ep_final, G * 2); A(rec_key, R * 2 * KW); A(rec_policy, R * C); A(rec_visits, R * C);
+        A(rec_last, R); A(rec_action, R);
+    }
+#undef A
+    if (rc != AF_OK) { af_engine_destroy(e); return rc; }
+    // initial state
+    std::vector<int32_t> ph(G, mode == AF_MODE_SELFPLAY ? PH_MOVE_START : PH_IDLE), rl(G, -1);
+    std::vector<double> tau(G, cfg->init_temp);
+    HIP_OK(hipMemcpy(P.phase, ph.data(), G * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(P.root_last, rl.data(), G * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(P.tau, tau.data(), G * 8, hipMemcpyHostToDevice));
+    e->h_i32.resize(G); e->h_seq.resize(G); e->h_popped.assign(G, 0); e->h_ct.resize(G * CT_N);
+    *out = e;
+    return AF_OK;
+}
+
+void af_engine_destroy(af_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+int32_t af_engine_num_games(const af_engine* e) { return e->P.G; }
+int32_t af_engine_cells(const af_engine* e) { return e->P.C; }
+int32_t af_engine_key_words(const af_engine* e) { return 2 * e->KW; }
+int32_t af_engine_max_plies(const af_engine* e) { return e->P.max_ply; }
+
+int af_engine_tick(af_engine* e, void* stream, const float* policy_dev, const float* value_dev, float* planes_dev) {
+    if (!e || !planes_dev) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (e->KW == 2) hipLaunchKernelGGL(af_tick_kernel<2>, dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev, planes_dev);
+    else hipLaunchKernelGGL(af_tick_kernel<4>, dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev, planes_dev);
+    HIP_OK(hipGetLastError());
+    return AF_OK;
+}
+
+int af_engine_status(af_engine* e, void* stream, int32_t* status_host) {
+    if (!e || !status_host) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemcpyAsync(status_host, e->P.status, (size_t)e->P.G * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (int g = 0; g < e->P.G; ++g) if (status_host[g] < 0) return status_host[g];
+    return AF_OK;
+}
+
+int af_engine_set_training(af_engine* e, int32_t training) {
+    if (!e) return AF_ERR_ARG;
+    e->P.training = training ? 1 : 0;
+    return AF_OK;
+}
+
+int af_engine_set_root(af_engine* e, int32_t game, const uint64_t* key, int32_t last_cell, int32_t random_a,
+                       int32_t reset_tree) {
+    if (!e || !key || game < 0 || game >= e->P.G || e->P.mode != AF_MODE_EXTERNAL) return AF_ERR_ARG;
+    EngineParams& P = e->P;
+    const int KW = e->KW;
+    HIP_OK(hipDeviceSynchronize());
+    if (reset_tree) {   // Player.reset(): player.py:48-51
+        const size_t hcap = (size_t)P.hash_mask + 1;
+        HIP_OK(hipMemset(P.hash + (size_t)game * hcap, 0, hcap * 4));
+        int32_t zero = 0;
+        HIP_OK(hipMemcpy(P.nodes + game, &zero, 4, hipMemcpyHostToDevice));
+        double tau = P.init_temp;
+        HIP_OK(hipMemcpy(P.tau + game, &tau, 8, hipMemcpyHostToDevice));
+        uint32_t ep;
+        HIP_OK(hipMemcpy(&ep, P.episode + game, 4, hipMemcpyDeviceToHost));
+        ep += 1;
+        HIP_OK(hipMemcpy(P.episode + game, &ep, 4, hipMemcpyHostToDevice));
+        uint32_t z = 0;
+        HIP_OK(hipMemcpy(P.sel + game, &z, 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(P.plyctr + game, &z, 4, hipMemcpyHostToDevice));
+    }
+    HIP_OK(hipMemcpy(P.root + (size_t)game * 2 * KW, key, (size_t)2 * KW * 8, hipMemcpyHostToDevice));
+    int32_t v = last_cell;
+    HIP_OK(hipMemcpy(P.root_last + game, &v, 4, hipMemcpyHostToDevice));
+    v = random_a ? 1 : 0;
+    HIP_OK(hipMemcpy(P.random_a + game, &v, 4, hipMemcpyHostToDevice));
+    v = PH_MOVE_START;
+    HIP_OK(hipMemcpy(P.phase + game, &v, 4, hipMemcpyHostToDevice));
+    v = 0;
+    HIP_OK(hipMemcpy(P.pending + game, &v, 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(P.status + game, &v, 4, hipMemcpyHostToDevice));
+    return AF_OK;
+}
+
+int af_engine_move_result(af_engine* e, int32_t game, int32_t* action_cell, int32_t* has_policy, float* policy,
+                          int32_t* visits, double* tau) {
+    if (!e || game < 0 || game >= e->P.G) return AF_ERR_ARG;
+    EngineParams& P = e->P;
+    const int CP = 64 * e->KW;
+    HIP_OK(hipDeviceSynchronize());
+    int32_t ph;
+    HIP_OK(hipMemcpy(&ph, P.phase + game, 4, hipMemcpyDeviceToHost));
+    if (ph == PH_ERROR) { int32_t st; HIP_OK(hipMemcpy(&st, P.status + game, 4, hipMemcpyDeviceToHost)); return st; }
+    if (ph != PH_MOVE_DONE) return AF_ERR_STATE;
+    if (action_cell) HIP_OK(hipMemcpy(action_cell, P.action + game, 4, hipMemcpyDeviceToHost));
+    if (has_policy) HIP_OK(hipMemcpy(has_policy, P.has_policy + game, 4, hipMemcpyDeviceToHost));
+    if (policy) HIP_OK(hipMemcpy(policy, P.policy + (size_t)game * CP, (size_t)P.C * 4, hipMemcpyDeviceToHost));
+    if (visits) HIP_OK(hipMemcpy(visits, P.visits + (size_t)game * CP, (size_t)P.C * 4, hipMemcpyDeviceToHost));
+    if (tau) HIP_OK(hipMemcpy(tau, P.tau + game, 8, hipMemcpyDeviceToHost));
+    return AF_OK;
+}
+
+int af_engine_pop_episodes(af_engine* e, void* stream, int32_t cap, int32_t* meta, float* final_value,
+                           uint64_t* keys, float* policies, int32_t* visits, int32_t* lasts, int32_t* actions) {
+    if (!e || e->P.mode != AF_MODE_SELFPLAY || cap < 0) return AF_ERR_ARG;
+    EngineParams& P = e->P;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = P.G, C = P.C, KW2 = 2 * e->KW, MP = P.max_ply;
+    HIP_OK(hipMemcpyAsync(e->h_seq.data(), P.ep_seq, (size_t)G * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    int n = 0;
+    bool changed = false;
+    for (int g = 0; g < G && n < cap; ++g) {
+        while (e->h_popped[g] != e->h_seq[g] && n < cap) {
+            const uint32_t seq = e->h_popped[g];
+            const size_t b = (size_t)g * 2 + (seq & 1u);
+            int32_t T;
+            HIP_OK(hipMemcpy(&T, P.ep_len + b, 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(final_value + n, P.ep_final + b, 4, hipMemcpyDeviceToHost));
+            meta[4 * n] = g; meta[4 * n + 1] = (int32_t)seq; meta[4 * n + 2] = T; meta[4 * n + 3] = 0;
+            const size_t r = b * MP;
+            HIP_OK(hipMemcpy(keys + (size_t)n * MP * KW2, P.rec_key + r * KW2, (size_t)T * KW2 * 8, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(policies + (size_t)n * MP * C, P.rec_policy + r * C, (size_t)T * C * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(visits + (size_t)n * MP * C, P.rec_visits + r * C, (size_t)T * C * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(lasts + (size_t)n * MP, P.rec_last + r, (size_t)T * 4, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(actions + (size_t)n * MP, P.rec_action + r, (size_t)T * 4, hipMemcpyDeviceToHost));
+            e->h_popped[g] = seq + 1;
+            changed = true;
+            ++n;
+        }
+    }
+    if (changed) HIP_OK(hipMemcpy(P.ep_popped, e->h_popped.data(), (size_t)G * 4, hipMemcpyHostToDevice));
+    return n;
+}
+
+int af_engine_counters(af_engine* e, void* stream, uint64_t* out) {
+    if (!e || !out) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = e->P.G;
+    HIP_OK(hipMemcpyAsync(e->h_ct.data(), e->P.counters, (size_t)G * CT_N * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(e->h_i32.data(), e->P.nodes, (size_t)G * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (int i = 0; i < CT_N; ++i) out[i] = 0;
+    for (int g = 0; g < G; ++g) {
+        for (int i = 0; i < CT_N; ++i) out[i] += e->h_ct[(size_t)g * CT_N + i];
+        out[7] += (uint64_t)e->h_i32[g];
+    }
+    return AF_OK;
+}
+
+int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys, int32_t* sum_n, int32_t* n,
+                        float* w, float* p, uint8_t* f32) {
+    if (!e || game < 0 || game >= e->P.G) return AF_ERR_ARG;
+    EngineParams& P = e->P;
+    const int KW2 = 2 * e->KW, CP = 64 * e->KW, C = P.C;
+    HIP_OK(hipDeviceSynchronize());
+    int32_t cnt;
+    HIP_OK(hipMemcpy(&cnt, P.nodes + game, 4, hipMemcpyDeviceToHost));
+    const int m = cnt < cap ? cnt : cap;
+    if (m <= 0) return cnt;
+    std::vector<int32_t> bn((size_t)m * CP);
+    std::vector<float> bw((size_t)m * CP), bp((size_t)m * CP);
+    const size_t nb = (size_t)game * P.node_cap;
+    HIP_OK(hipMemcpy(keys, P.node_key + nb * KW2, (size_t)m * KW2 * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(sum_n, P.node_sum + nb, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(bn.data(), P.edge_n + nb * CP, (size_t)m * CP * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(bw.data(), P.edge_w + nb * CP, (size_t)m * CP * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(bp.data(), P.edge_p + nb * CP, (size_t)m * CP * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; ++i)
+        for (int c = 0; c < C; ++c) {
+            const int32_t raw = bn[(size_t)i * CP + c];
+            n[(size_t)i * C + c] = raw & 0x7fffffff;
+            f32[(size_t)i * C + c] = raw < 0 ? 1 : 0;
+            w[(size_t)i * C + c] = bw[(size_t)i * CP + c];
+            p[(size_t)i * C + c] = bp[(size_t)i * CP + c];
+        }
+    return cnt;
+}
+
+// utils.py:178-196 state_to_board, straight into a key
+int af_state_to_key(const char* state, int32_t S, uint64_t* key) {
+    if (!state || !key || S < 1 || S * S > 256) return AF_ERR_ARG;
+    const int KW = S * S <= 128 ? 2 : 4;
+    for (int k = 0; k < 2 * KW; ++k) key[k] = 0;
+    int i = 0, j = 0;
+    for (const char* p = state; *p; ++p) {
+        const char ch = *p;
+        if (ch == '/') { ++i; j = 0; }
+        else if (ch >= 'a' && ch <= 'z') j += ch - 'a';
+        else if (ch == '3' || ch == '1') {
+            if (i >= S || j >= S) return AF_ERR_ARG;
+            const int c = i * S + j;
+            key[(ch == '3' ? 0 : KW) + (c >> 6)] |= 1ull << (c & 63);
+            ++j;
+        } else return AF_ERR_ARG;
+    }
+    return AF_OK;
+}
+
+// utils.py:156-175 board_to_state from a key
+int af_key_to_state(const uint64_t* key, int32_t S, char* out, int32_t cap) {
+    if (!key || !out || S < 1 || S * S > 256) return AF_ERR_ARG;
+    const int KW = S * S <= 128 ? 2 : 4;
+    int n = 0;
+    for (int i = 0; i < S; ++i) {
+        int run = 0;
+        for (int j = 0; j < S; ++j) {
+            const int c = i * S + j;
+            const bool m = (key[c >> 6] >> (c & 63)) & 1ull, t = (key[KW + (c >> 6)] >> (c & 63)) & 1ull;
+            if (!m && !t) { ++run; continue; }
+            if (run) { if (n + 1 >= cap) return AF_ERR_ARG; out[n++] = (char)('a' + run); run = 0; }
+            if (n + 1 >= cap) return AF_ERR_ARG;
+            out[n++] = m ? '3' : '1';
+        }
+        if (run) { if (n + 1 >= cap) return AF_ERR_ARG; out[n++] = (char)('a' + run); }
+        if (n + 1 >= cap) return AF_ERR_ARG;
+        out[n++] = '/';
+    }
+    out[n] = 0;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""ctypes binding of the C-ABI HIP engine (include/af_engine.h) and the batched
+self-play driver that replaces main.py:82-94 gen_data + genData/networkAPI.py.
+
+No CPU fallback: if libaf_hip.so is missing or fails to load this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_PKG, "_lib", "libaf_hip.so")
+
+MODE_SELFPLAY, MODE_EXTERNAL = 0, 1
+STATUS_IDLE, STATUS_NEED_EVAL, STATUS_MOVE_DONE = 0, 1, 2
+BLACK_WIN, WHITE_WIN, DRAW = 1, -1, 0          # utils.py:9-11
+
+CFG_ATTRS = ("board_size", "goal", "simulation_per_step", "upper_simulation_per_step", "init_temp", "gamma",
+             "tau_decay_rate", "tau_decay_rate_r", "dirichlet_alpha", "c_puct")
+
+
+class AfConfig(C.Structure):
+    _fields_ = [("board_size", C.c_int32), ("goal", C.c_int32), ("simulation_per_step", C.c_int32),
+                ("upper_simulation_per_step", C.c_int32), ("init_temp", C.c_double), ("gamma", C.c_double),
+                ("tau_decay_rate", C.c_double), ("tau_decay_rate_r", C.c_double), ("dirichlet_alpha", C.c_double),
+                ("c_puct", C.c_double)]
+
+    @classmethod
+    def from_cfg(cls, cfg):
+        """cfg: the reference's config module or any attribute bag with its names (player.py reads
+        board_size, goal, init_temp, gamma, tau_decay_rate(_r), simulation_per_step,
+        upper_simulation_per_step, dirichlet_alpha, c_puct)."""
+        return cls(*[getattr(cfg, a) for a in CFG_ATTRS])
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libaf_hip.so (built by alphafive_amd.build / __graft_entry__.build). Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise EngineError(f"{_LIBPATH} not found: build the HIP engine first "
+                              f"(python -m alphafive_amd.build). There is no CPU fallback.")
+        L = C.CDLL(_LIBPATH)
+        vp = C.c_void_p
+        i32p, f32p, u64p, u8p = (C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint8))
+        L.af_abi_version.restype = C.c_int
+        L.af_strerror.restype = C.c_char_p
+        L.af_strerror.argtypes = [C.c_int]
+        L.af_engine_create.argtypes = [C.POINTER(AfConfig), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                       C.c_uint32, C.c_int32, C.POINTER(vp)]
+        L.af_engine_destroy.argtypes = [vp]
+        L.af_engine_destroy.restype = None
+        for fn in ("af_engine_num_games", "af_engine_cells", "af_engine_key_words", "af_engine_max_plies"):
+            getattr(L, fn).argtypes = [vp]
+            getattr(L, fn).restype = C.c_int32
+        L.af_engine_tick.argtypes = [vp, vp, vp, vp, vp]
+        L.af_engine_status.argtypes = [vp, vp, i32p]
+        L.af_engine_set_root.argtypes = [vp, C.c_int32, u64p, C.c_int32, C.c_int32, C.c_int32]
+        L.af_engine_move_result.argtypes = [vp, C.c_int32, i32p, i32p, f32p, i32p, C.POINTER(C.c_double)]
+        L.af_engine_set_training.argtypes = [vp, C.c_int32]
+        L.af_engine_pop_episodes.argtypes = [vp, vp, C.c_int32, i32p, f32p, u64p, f32p, i32p, i32p, i32p]
+        L.af_engine_counters.argtypes = [vp, vp, u64p]
+        L.af_engine_tree_dump.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
+        L.af_state_to_key.argtypes = [C.c_char_p, C.c_int32, u64p]
+        L.af_key_to_state.argtypes = [u64p, C.c_int32, C.c_char_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise EngineError(f"{what}: {lib().af_strerror(rc).decode()} (code {rc})")
+    return rc
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def key_words(S):
+    return 4 if S * S <= 128 else 8
+
+
+def state_to_key(state, S):
+    key = np.zeros(key_words(S), np.uint64)
+    _check(lib().af_state_to_key(state.encode(), S, _p(key, C.c_uint64)), "af_state_to_key")
+    return key
+
+
+def key_to_state(key, S):
+    key = np.ascontiguousarray(key, np.uint64)
+    out = C.create_string_buffer(288)
+    _check(lib().af_key_to_state(_p(key, C.c_uint64), S, out, 288), "af_key_to_state")
+    return out.value.decode()
+
+
+COUNTER_NAMES = ("sims", "selects", "expands", "terminals", "plies", "episodes", "legal_sum", "nodes")
+
+
+class Engine:
+    """Thin RAII wrapper over af_engine_* (one handle per GPU)."""
+
+    def __init__(self, cfg, num_games, device=0, mode=MODE_SELFPLAY, training=True, seed=0, first_game_id=0,
+                 node_cap=0):
+        self._h = C.c_void_p()
+        self.cfg = AfConfig.from_cfg(cfg) if not isinstance(cfg, AfConfig) else cfg
+        _check(lib().af_engine_create(C.byref(self.cfg), num_games, device, mode, int(training), seed, first_game_id,
+                                      node_cap, C.byref(self._h)), "af_engine_create")
+        self.G = num_games
+        self.S = self.cfg.board_size
+        self.C = self.S * self.S
+        self.KW2 = lib().af_engine_key_words(self._h)
+        self.max_plies = lib().af_engine_max_plies(self._h)
+        self.mode = mode
+        self.device = device
+        self._status = np.zeros(num_games, np.int32)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().af_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def tick(self, policy_ptr, value_ptr, planes_ptr, stream=None):
+        """Device pointers (ints): policy float32[G,C], value float32[G] (consumed by parked games),
+        planes float32[G,3,S,S] (written for every game that parks on a new leaf)."""
+        _check(lib().af_engine_tick(self._h, stream, policy_ptr, value_ptr, planes_ptr), "af_engine_tick")
+
+    def status(self, stream=None):
+        rc = lib().af_engine_status(self._h, stream, _p(self._status, C.c_int32))
+        _check(rc, "engine status")
+        return self._status
+
+    def set_training(self, training):
+        _check(lib().af_engine_set_training(self._h, int(training)), "af_engine_set_training")
+
+    def set_root(self, game, key, last_cell=-1, random_a=False, reset_tree=False):
+        key = np.ascontiguousarray(key, np.uint64)
+        _check(lib().af_engine_set_root(self._h, game, _p(key, C.c_uint64), last_cell, int(random_a), int(reset_tree)),
+               "af_engine_set_root")
+
+    def move_result(self, game):
+        a, hp, tau = C.c_int32(-1), C.c_int32(0), C.c_double(0)
+        pol = np.zeros(self.C, np.float32)
+        vis = np.zeros(self.C, np.int32)
+        _check(lib().af_engine_move_result(self._h, game, C.byref(a), C.byref(hp), _p(pol, C.c_float),
+                                           _p(vis, C.c_int32), C.byref(tau)), "af_engine_move_result")
+        return a.value, (pol if hp.value else None), vis, tau.value
+
+    def counters(self, stream=None):
+        out = np.zeros(8, np.uint64)
+        _check(lib().af_engine_counters(self._h, stream, _p(out, C.c_uint64)), "af_engine_counters")
+        return {k: int(v) for k, v in zip(COUNTER_NAMES, out)}
+
+    def tree_dump(self, game):
+        cnt = _check(lib().af_engine_tree_dump(self._h, game, 0, None, None, None, None, None, None), "tree_dump")
+        keys = np.zeros((cnt, self.KW2), np.uint64)
+        sum_n = np.zeros(cnt, np.int32)
+        n = np.zeros((cnt, self.C), np.int32)
+        w = np.zeros((cnt, self.C), np.float32)
+        p = np.zeros((cnt, self.C), np.float32)
+        f = np.zeros((cnt, self.C), np.uint8)
+        if cnt:
+            _check(lib().af_engine_tree_dump(self._h, game, cnt, _p(keys, C.c_uint64), _p(sum_n, C.c_int32),
+                                             _p(n, C.c_int32), _p(w, C.c_float), _p(p, C.c_float), _p(f, C.c_uint8)),
+                   "tree_dump")
+        return dict(keys=keys, sum_n=sum_n, n=n, w=w, p=p, f32=f)
+
+    def pop_episodes_raw(self, cap=256, stream=None):
+        MP, Cc, K = self.max_plies, self.C, self.KW2
+        meta = np.zeros((cap, 4), np.int32)
+        fv = np.zeros(cap, np.float32)
+        keys = np.zeros((cap, MP, K), np.uint64)
+        pol = np.zeros((cap, MP, Cc), np.float32)
+        vis = np.zeros((cap, MP, Cc), np.int32)
+        last = np.zeros((cap, MP), np.int32)
+        act = np.zeros((cap, MP), np.int32)
+        n = _check(lib().af_engine_pop_episodes(self._h, stream, cap, _p(meta, C.c_int32), _p(fv, C.c_float),
+                                                _p(keys, C.c_uint64), _p(pol, C.c_float), _p(vis, C.c_int32),
+                                                _p(last, C.c_int32), _p(act, C.c_int32)), "af_engine_pop_episodes")
+        out = []
+        for i in range(n):
+            T = int(meta[i, 2])
+            out.append(dict(game=int(meta[i, 0]), seq=int(meta[i, 1]), T=T, final_value=float(fv[i]),
+                            keys=keys[i, :T].copy(), policies=pol[i, :T].copy(), visits=vis[i, :T].copy(),
+                            lasts=last[i, :T].copy(), actions=act[i, :T].copy()))
+        return out
+
+
+def assemble_episode(raw, S, gamma):
+    """Player.run's tail (player.py:73-82) + main.gen_data's result code (main.py:85-93):
+    raw device records -> ([(state, policy[S,S], last_action, value, weight)], result)."""
+    from . import utils
+    T = raw["T"]
+    value = float(raw["final_value"])
+    if T % 2 == 1:
+        value = -value
+    weights = utils.construct_weights(T, gamma=gamma)
+    rec = []
+    for t in range(T):
+        la = None if raw["lasts"][t] < 0 else (int(raw["lasts"][t]) // S, int(raw["lasts"][t]) % S)
+        rec.append((key_to_state(raw["keys"][t], S), raw["policies"][t].reshape(S, S).copy(), la, value, weights[t]))
+        value = -value
+    last_value = rec[-1][-2]
+    if last_value == 0.0:
+        result = DRAW
+    elif T % 2 == 1:
+        result = BLACK_WIN
+    else:
+        result = WHITE_WIN
+    return rec, result
+
+
+class SelfPlayEngine:
+    """G concurrent self-play games on one GPU: the device-resident replacement of
+    main.py:50-55 (5 worker processes running Player.run) + NetworkAPI batching.
+
+    pv_device: callable planes float32[G,3,S,S] (torch, on device) -> (policy[G,C], value[G])
+    torch tensors on the same device — alphafive_amd.network.ResNet.eval_device, or a test stub.
+    """
+
+    def __init__(self, cfg, num_games, pv_device, device=0, seed=0, first_game_id=0, training=True, node_cap=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise EngineError("SelfPlayEngine needs a HIP device (torch.cuda.is_available() is False)")
+        self.torch = torch
+        self.cfg = cfg
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.engine = Engine(cfg, num_games, device=device, mode=MODE_SELFPLAY, training=training, seed=seed,
+                             first_game_id=first_game_id, node_cap=node_cap)
+        S = cfg.board_size
+        self.G, self.S, self.C = num_games, S, S * S
+        self.planes = torch.zeros((num_games, 3, S, S), dtype=torch.float32, device=self.dev)
+        self.policy = torch.zeros((num_games, S * S), dtype=torch.float32, device=self.dev)
+        self.value = torch.zeros((num_games,), dtype=torch.float32, device=self.dev)
+        self.pv_device = pv_device
+        self.ticks = 0
+
+    def tick(self):
+        """One simulation step for every game: tree kernel -> leaf batch -> net."""
+        torch = self.torch
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.engine.tick(self.policy.data_ptr(), self.value.data_ptr(), self.planes.data_ptr(), stream)
+        p, v = self.pv_device(self.planes)
+        if p.data_ptr() != self.policy.data_ptr():
+            self.policy.copy_(p.reshape(self.G, self.C))
+        if v.data_ptr() != self.value.data_ptr():
+            self.value.copy_(v.reshape(self.G))
+        self.ticks += 1
+
+    def run_ticks(self, n, check_every=0):
+        for i in range(n):
+            self.tick()
+            if check_every and (i + 1) % check_every == 0:
+                self.check()
+
+    def check(self):
+        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+        return self.engine.status(stream)
+
+    def counters(self):
+        return self.engine.counters(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def pop_raw(self, cap=256):
+        return self.engine.pop_episodes_raw(cap, self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def pop_episodes(self, cap=256):
+        """-> list of (game_record, result) exactly as main.gen_data puts on its queue (main.py:94)."""
+        return [assemble_episode(r, self.S, self.cfg.gamma) for r in self.pop_raw(cap)]
+
+    def close(self):
+        self.engine.close()

@@ -1,0 +1,205 @@
+"""Drop-in for the reference's genData/player.py:Player on the HIP engine.
+
+Same constructor, methods, argument meaning, return types and error behaviour:
+
+    Player(cfg=None, training=True, pipe=None, pv_fn=None)      player.py:23-35
+    .get_init_state() -> str                                    player.py:37
+    .reset(search_tree=None)                                    player.py:48
+    .run(e=0.25) -> [(state, policy[S,S], last_action, value, weight)]   player.py:53
+    .get_action(state, e=0.25, last_action=None, random_a=False) -> (policy|None, (i,j))  player.py:128
+    .pruning_tree(board, state=None)                            player.py:149
+    .close()                                                    player.py:281
+    attributes: tree, root_state, tau, training, config
+
+The search itself (MCTS_search / select / expand / backup / calc_policy) runs in the
+device engine (csrc/af_engine.hip) in EXTERNAL mode with one resident game; this class only
+moves leaf planes / evaluations between the engine and the caller's pv_fn or pipe.
+Noise comes from the engine's counter-based generator (include/af_noise.h), not from
+np.random — seed it with the `seed` keyword.
+"""
+import gc
+from collections.abc import Mapping
+
+import numpy as np
+
+from . import engine as _eng
+from . import utils
+
+
+class _EdgeView(object):
+    __slots__ = ("n", "w", "q", "p")
+
+    def __init__(self, n, w, q, p):
+        self.n, self.w, self.q, self.p = n, w, q, p
+
+
+class _StateView(object):
+    """Read-only stand-in for player.py:16 State: .a maps (i,j) -> edge stats, .sum_n."""
+
+    def __init__(self, S, legal_cells, sum_n, n, w, p, f32):
+        self.sum_n = int(sum_n)
+        self.a = {}
+        for c in legal_cells:
+            nn = int(n[c])
+            if nn == 0:
+                q = 0
+            elif f32[c]:
+                q = np.float32(w[c]) / np.float32(nn)
+            else:
+                q = float(w[c]) / nn
+            self.a[(c // S, c % S)] = _EdgeView(nn, w[c] if f32[c] else float(w[c]), q, p[c])
+
+
+class TreeView(Mapping):
+    """Snapshot of the device transposition store keyed by state string (player.py:29)."""
+
+    def __init__(self, dump, S):
+        self._S = S
+        self._d = dump
+        self._index = {_eng.key_to_state(dump["keys"][i], S): i for i in range(len(dump["sum_n"]))}
+
+    def __getitem__(self, state):
+        i = self._index[state]
+        S, C = self._S, self._S * self._S
+        key = self._d["keys"][i]
+        kw = len(key) // 2
+        occ = [(int(key[c >> 6]) | int(key[kw + (c >> 6)])) >> (c & 63) & 1 for c in range(C)]
+        legal = [c for c in range(C) if not occ[c]]
+        return _StateView(S, legal, self._d["sum_n"][i], self._d["n"][i], self._d["w"][i], self._d["p"][i],
+                          self._d["f32"][i])
+
+    def __iter__(self):
+        return iter(self._index)
+
+    def __len__(self):
+        return len(self._index)
+
+
+class Player(object):
+    def __init__(self, cfg=None, training=True, pipe=None, pv_fn=None, device=0, seed=0, game_id=0, node_cap=0):
+        assert pipe is not None or pv_fn is not None
+        import torch
+        self.config = cfg
+        self.training = training
+        self.root_state = None
+        self.goal = self.config.goal
+        self.tau = self.config.init_temp
+        self.pipe = pipe
+        self.job_done = False
+        self.pv_fn = pv_fn
+        self._torch = torch
+        self._S = cfg.board_size
+        self._C = self._S * self._S
+        self._dev = torch.device("cuda", device)
+        self._engine = _eng.Engine(cfg, 1, device=device, mode=_eng.MODE_EXTERNAL, training=training, seed=seed,
+                                   first_game_id=game_id, node_cap=node_cap)
+        self._planes = torch.zeros((1, 3, self._S, self._S), dtype=torch.float32, device=self._dev)
+        self._policy = torch.zeros((1, self._C), dtype=torch.float32, device=self._dev)
+        self._value = torch.zeros((1,), dtype=torch.float32, device=self._dev)
+        self._reset_pending = False
+        owner = getattr(pv_fn, "__self__", None)
+        self._pv_device = getattr(owner, "eval_device", None) if pv_fn is not None else None
+        self.last_visits = None
+
+    # -- player.py:37-46
+    def get_init_state(self):
+        return (chr(ord("a") + self.config.board_size) + "/") * self.config.board_size
+
+    # -- player.py:48-51
+    def reset(self, search_tree=None):
+        if search_tree is not None and len(search_tree):
+            raise NotImplementedError("adopting a foreign search tree is not supported by the device store")
+        self._reset_pending = True
+        self.root_state = None
+        self.tau = self.config.init_temp
+
+    @property
+    def tree(self):
+        if self._reset_pending:
+            return TreeView(dict(keys=np.zeros((0, self._engine.KW2), np.uint64), sum_n=np.zeros(0, np.int32),
+                                 n=None, w=None, p=None, f32=None), self._S)
+        return TreeView(self._engine.tree_dump(0), self._S)
+
+    # -- player.py:186-197: the evaluation plug-in (pv_fn or pipe)
+    def _evaluate_leaf(self):
+        if self._pv_device is not None:
+            p, v = self._pv_device(self._planes)
+            self._policy.copy_(p.reshape(1, self._C))
+            self._value.copy_(v.reshape(1))
+            return
+        x = self._planes.cpu().numpy()
+        if self.pv_fn is not None:
+            policy, value = self.pv_fn(x)
+            policy, value = policy[0], value[0]
+        else:
+            self.pipe.send([x[0]])
+            while not self.pipe.poll():
+                pass
+            policy, value = self.pipe.recv()[0]
+        self._policy.copy_(self._torch.from_numpy(np.ascontiguousarray(policy, np.float32).reshape(1, self._C)))
+        self._value.copy_(self._torch.from_numpy(np.asarray([value], np.float32)))
+
+    # -- player.py:128-147
+    def get_action(self, state, e=0.25, last_action=None, random_a=False):
+        self.root_state = state
+        S = self._S
+        key = _eng.state_to_key(state, S)
+        last_cell = -1 if last_action is None else last_action[0] * S + last_action[1]
+        self._engine.set_training(self.training)
+        self._engine.set_root(0, key, last_cell, random_a, reset_tree=self._reset_pending)
+        self._reset_pending = False
+        stream = self._torch.cuda.current_stream(self._dev).cuda_stream
+        while True:
+            self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), stream)
+            st = int(self._engine.status(stream)[0])
+            if st == _eng.STATUS_NEED_EVAL:
+                self._evaluate_leaf()
+            elif st == _eng.STATUS_MOVE_DONE:
+                break
+            else:
+                raise _eng.EngineError(f"unexpected engine status {st}")
+        action, policy, visits, tau = self._engine.move_result(0)
+        self.tau = tau
+        self.last_visits = visits
+        if policy is not None:
+            policy = policy.reshape(S, S)
+        return policy, (action // S, action % S)
+
+    # -- player.py:53-82
+    def run(self, e=0.25):
+        S = self._S
+        state = self.get_init_state()
+        game_over = False
+        data = []
+        value = 0
+        last_action = None
+        while not game_over:
+            policy, action = self.get_action(state, e, last_action)
+            data.append((state, policy, last_action))
+            board = utils.step(utils.state_to_board(state, S), action)
+            state = utils.board_to_state(board)
+            game_over, value = utils.is_game_over(board, self.goal)
+            last_action = action
+        self.reset()
+        turns = len(data)
+        if turns % 2 == 1:
+            value = -value
+        weights = utils.construct_weights(turns, gamma=self.config.gamma)
+        final_data = []
+        for i in range(turns):
+            final_data.append((*data[i], value, weights[i]))
+            value = -value
+        return final_data
+
+    # -- player.py:149-164: the reference's pruning only frees memory; the device store compacts
+    # itself under capacity pressure, so this is an API-compatible no-op.
+    def pruning_tree(self, board, state=None):
+        return None
+
+    # -- player.py:281-284
+    def close(self):
+        self.job_done = True
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        gc.collect()

@@ -1,0 +1,116 @@
+"""Host-side mirror of the reference's utils.py game helpers (utils.py:149-296) and replay
+record conventions.  Same names, arguments and results (bit-for-bit; checked against golden
+vectors recorded from the reference in tests/test_host_utils.py), written on numpy
+vector ops.  The device engine has its own bitboard versions of these rules
+(csrc/af_engine.hip); these exist for the API boundary (state strings, records).
+
+Board convention (utils.py:185,194,275-283): int8[S,S], +1 = stone of the player to move,
+-1 = opponent, 0 = empty.
+"""
+import numpy as np
+
+BLACK_WIN = 1      # utils.py:9-11
+WHITE_WIN = -1
+DRAW = 0
+
+
+def board_to_state(board):
+    """utils.py:156-175 — run-length text key: empties as chr(ord('a')+run), '3' mine, '1' theirs, '/' per row."""
+    rows = []
+    for row in np.asarray(board):
+        out, run = [], 0
+        for v in row.tolist():
+            if v == 0:
+                run += 1
+                continue
+            if run:
+                out.append(chr(97 + run))
+                run = 0
+            out.append(str(v + 2))
+        if run:
+            out.append(chr(97 + run))
+        rows.append("".join(out))
+    return "/".join(rows) + "/"
+
+
+def state_to_board(state, board_size):
+    """utils.py:178-196."""
+    board = np.zeros((board_size, board_size), np.int8)
+    for i, row in enumerate(state.split("/")[:board_size]):
+        j = 0
+        for ch in row:
+            if ch.isalpha():
+                j += ord(ch) - 97
+            else:
+                board[i, j] = int(ch) - 2
+                j += 1
+    return board
+
+
+def is_game_over(board, goal):
+    """utils.py:199-235 — (over, value from the player-to-move's view).  The reference scans cells
+    row-major and at each cell tests down, right, down-right, up-right windows of `goal`; the first
+    hit in that order wins (matters only if both colours have a line)."""
+    b = np.asarray(board, np.int32)
+    h, w = b.shape
+    best = None   # (cell*4+dir, value)
+    if goal <= h:
+        win = np.lib.stride_tricks.sliding_window_view
+        cands = []
+        if h >= goal:
+            s = win(b, goal, axis=0).sum(-1)                               # down: anchor (i,j), i<=h-goal
+            cands.append((0, s, 0, 0))
+            s = win(b, goal, axis=1).sum(-1)                               # right: anchor (i,j), j<=w-goal
+            cands.append((1, s, 0, 0))
+            idx = np.arange(goal)
+            d = win(b, (goal, goal))                                       # [h-g+1, w-g+1, g, g]
+            cands.append((2, d[:, :, idx, idx].sum(-1), 0, 0))             # down-right from (i,j)
+            cands.append((3, d[:, :, idx[::-1], idx].sum(-1), goal - 1, 0))  # up-right from (i+g-1, j)
+        for direction, s, di, dj in cands:
+            hit = np.argwhere(np.abs(s) == goal)
+            for i, j in hit:
+                key = ((i + di) * w + (j + dj)) * 4 + direction
+                if best is None or key < best[0]:
+                    best = (key, 1.0 if s[i, j] > 0 else -1.0)
+    if best is not None:
+        return True, best[1]
+    if not (b == 0).any():
+        return True, 0.0
+    return False, 0.0
+
+
+def get_legal_actions(board):
+    """utils.py:238-245 — empties in row-major order; this order defines edge index everywhere."""
+    ii, jj = np.nonzero(np.asarray(board) == 0)
+    return [(int(i), int(j)) for i, j in zip(ii, jj)]
+
+
+def board_to_inputs(board, type_=np.float32, last_action=None):
+    """utils.py:256-272 — planes [mine, theirs, one-hot(last_action)]."""
+    b = np.asarray(board)
+    out = np.zeros((3,) + b.shape, dtype=type_)
+    out[0] = b == 1
+    out[1] = b == -1
+    if last_action is not None:
+        out[2, last_action[0], last_action[1]] = 1
+    return out
+
+
+def step(board, action):
+    """utils.py:275-283 — place a stone for the player to move, flip perspective (mutates like the reference)."""
+    board[action[0], action[1]] = 1
+    return -board
+
+
+def construct_weights(length, gamma=0.95):
+    """utils.py:286-296 — per-ply training weights, fp32: w[T-1]=1, w[i]=w[i+1]*gamma, then T*w/sum(w)."""
+    length = int(length)
+    g = np.full(length, np.float32(gamma), np.float32)
+    g[0] = np.float32(1.0)
+    w = np.multiply.accumulate(g, dtype=np.float32)[::-1].copy()        # sequential fp32 products
+    return length * w / np.sum(w)
+
+
+def softmax(x):
+    e = np.exp(x - np.max(x))
+    return e / np.sum(e)

@@ -1,0 +1,133 @@
+/*
+ * af_engine.h — C ABI of the MI355X-native alphaFive self-play engine (libaf_hip.so).
+ *
+ * Drop-in boundary for ONE path of GuoYi0/alphaFive: MCTS self-play move
+ * generation.  The reference implements it in Python (no FFI of its own); a
+ * maintainer binds these entry points with ctypes from
+ *   genData/player.py:23-284   Player.get_action / run / MCTS_search / select /
+ *                              evaluate_and_expand / update_tree / calc_policy
+ *   utils.py:149-296           state codec, is_game_over, legal moves, inputs
+ *   genData/networkAPI.py:43   leaf batching (replaced by the device leaf batch)
+ *   main.py:82-94              gen_data episode hand-off
+ *
+ * Conventions: plain pointers and sizes, int return codes (0 = ok, <0 = error,
+ * see af_strerror), caller-allocated outputs, no exceptions across the ABI, one
+ * engine handle per GPU, a handle is not thread-safe.  `*_dev` pointers are HIP
+ * device pointers on the engine's device (e.g. torch tensors' data_ptr()).
+ *
+ * Board convention everywhere (utils.py:185,194,275-283): cell c = i*S + j,
+ * +1 = stone of the player to move ("mine"), -1 = opponent ("theirs").
+ * A position key is 2*KW uint64 words: mine bitboard then theirs bitboard,
+ * bit c of word c>>6; KW = 2 for S*S <= 128, 4 for S*S <= 256.
+ */
+#ifndef AF_ENGINE_H
+#define AF_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AF_ABI_VERSION 1
+
+/* engine modes */
+#define AF_MODE_SELFPLAY 0   /* Player.run loop on device: games restart forever (main.py:82 gen_data) */
+#define AF_MODE_EXTERNAL 1   /* Player.get_action: host sets roots, engine parks when a move is decided */
+
+/* per-game status after af_engine_tick */
+#define AF_STATUS_IDLE      0
+#define AF_STATUS_NEED_EVAL 1   /* a leaf's input planes were written; feed policy/value to the next tick */
+#define AF_STATUS_MOVE_DONE 2   /* EXTERNAL mode: read af_engine_move_result, then set the next root */
+
+/* error codes */
+#define AF_OK 0
+#define AF_ERR_ARG        (-1)
+#define AF_ERR_HIP        (-2)
+#define AF_ERR_NODE_CAP   (-3)  /* a game's transposition store is full */
+#define AF_ERR_NO_ROOT    (-4)  /* get_action on a finished position (reference: IndexError at player.py:102) */
+#define AF_ERR_EP_OVERRUN (-5)  /* finished episodes were not popped in time */
+#define AF_ERR_STATE      (-6)
+
+/* config.py:2-20 — the attributes Player reads (player.py:31,32,44,77,109,111,141,143,240,261) */
+typedef struct {
+    int32_t board_size;            /* config.py:2  */
+    int32_t goal;                  /* config.py:6  */
+    int32_t simulation_per_step;   /* config.py:4  */
+    int32_t upper_simulation_per_step; /* config.py:5 */
+    double init_temp;              /* config.py:19 */
+    double gamma;                  /* config.py:18 (host side: utils.construct_weights) */
+    double tau_decay_rate;         /* config.py:12 */
+    double tau_decay_rate_r;       /* config.py:15 */
+    double dirichlet_alpha;        /* config.py:17 */
+    double c_puct;                 /* config.py:16 */
+} af_config;
+
+typedef struct af_engine af_engine;
+
+/* Create an engine holding `num_games` concurrent games on HIP device `device`.
+ * training: Player(training=...) (player.py:23).  seed + (first_game_id + g) key the
+ * per-game noise streams (include/af_noise.h).  node_cap: transposition-store
+ * capacity per game in nodes (0 = default for the mode). */
+int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, int32_t mode, int32_t training,
+                     uint64_t seed, uint32_t first_game_id, int32_t node_cap, af_engine** out);
+void af_engine_destroy(af_engine* e);
+
+/* geometry */
+int32_t af_engine_num_games(const af_engine* e);
+int32_t af_engine_cells(const af_engine* e);        /* C = S*S            */
+int32_t af_engine_key_words(const af_engine* e);    /* 2*KW               */
+int32_t af_engine_max_plies(const af_engine* e);    /* C                  */
+
+/* One tick (player.py:204 MCTS_search, batched): every game first consumes the
+ * evaluation of the leaf it parked on (policy_dev[g][C] softmax probs, value_dev[g];
+ * player.py:186 evaluate_and_expand + :166 update_tree), then descends
+ * (terminal test utils.py:199, select player.py:230, step utils.py:275), finishing
+ * simulations that end in terminal positions and whole moves (player.py:84
+ * calc_policy) on the way, until it parks on the next unseen leaf, whose input
+ * planes (utils.py:256 board_to_inputs) it writes to planes_dev[g][3][S][S].
+ * Asynchronous on `stream` (a hipStream_t, NULL = default stream). */
+int af_engine_tick(af_engine* e, void* stream, const float* policy_dev, const float* value_dev, float* planes_dev);
+
+/* Copy per-game status words to the host (synchronises `stream`). Returns the
+ * first negative per-game error if any game failed, else 0. */
+int af_engine_status(af_engine* e, void* stream, int32_t* status_host);
+
+/* EXTERNAL mode: Player.get_action(state, last_action, random_a) for game g.
+ * key: 2*KW words.  last_cell: -1 for None.  reset_tree != 0: Player.reset() first. */
+int af_engine_set_root(af_engine* e, int32_t game, const uint64_t* key, int32_t last_cell, int32_t random_a,
+                       int32_t reset_tree);
+/* result of the finished move: action cell, temperature policy float32[C] (has_policy == 0
+ * when the reference returns None, player.py:106), root visit counts int32[C], tau after. */
+int af_engine_move_result(af_engine* e, int32_t game, int32_t* action_cell, int32_t* has_policy, float* policy,
+                          int32_t* visits, double* tau);
+int af_engine_set_training(af_engine* e, int32_t training);
+
+/* SELFPLAY mode: pop finished episodes (Player.run's return value before value/weight
+ * assembly, which is host-side arithmetic on T and final_value).
+ * meta[i] = {game, episode_seq, T, 0}; final_value[i] = is_game_over value of the last
+ * position; per ply: keys [cap][max_plies][2KW], policies/visits [cap][max_plies][C],
+ * lasts/actions [cap][max_plies].  Returns the number popped (<= cap) or <0. */
+int af_engine_pop_episodes(af_engine* e, void* stream, int32_t cap, int32_t* meta, float* final_value,
+                           uint64_t* keys, float* policies, int32_t* visits, int32_t* lasts, int32_t* actions);
+
+/* counters summed over games: out[0..7] = sims, selects, expands, terminal hits, plies,
+ * episodes, sum of L over selects, nodes currently stored */
+int af_engine_counters(af_engine* e, void* stream, uint64_t* out);
+
+/* tree inspection (tests / Player.tree): nodes of game g in storage order.
+ * n has the "w is fp32-typed" flag stripped into f32[]. Returns node count or <0. */
+int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys, int32_t* sum_n, int32_t* n,
+                        float* w, float* p, uint8_t* f32);
+
+/* state-string codec (utils.py:156-196) <-> position key */
+int af_state_to_key(const char* state, int32_t board_size, uint64_t* key);
+int af_key_to_state(const uint64_t* key, int32_t board_size, char* out, int32_t cap);
+
+const char* af_strerror(int code);
+int af_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AF_ENGINE_H */

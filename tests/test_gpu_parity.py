@@ -1,0 +1,161 @@
+"""Tier B (GPU box): the HIP engine, called through the C ABI, against the C oracle in
+AFO_RNG_PHILOX mode on the same seeded inputs.  Bit-exact: visit-count vectors, actions,
+temperature policies, tau, tree contents (N, W, dtype flag, P, sum_n), episode records."""
+import numpy as np
+import pytest
+
+import oracle
+import pseudonet
+from conftest import make_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _cell(S, a):
+    return None if a is None else a[0] * S + a[1]
+
+
+def _compare_tree(dev_dump, orc, S, root_state=None):
+    """Every device node equals the oracle's node; every oracle node that is still reachable
+    (stones superset of the root's) is present on the device."""
+    from alphafive_amd import engine as eng
+    od = orc.tree_dump()
+    omap = {od["keys"][i].tobytes(): i for i in range(len(od["sum_n"]))}
+    kw2 = dev_dump["keys"].shape[1]
+    seen = set()
+    for i in range(len(dev_dump["sum_n"])):
+        k = np.zeros(8, np.uint64)
+        kw = kw2 // 2
+        k[:kw] = dev_dump["keys"][i][:kw]
+        k[4:4 + kw] = dev_dump["keys"][i][kw:]
+        j = omap.get(k.tobytes())
+        assert j is not None, f"device node {i} unknown to the oracle: {eng.key_to_state(dev_dump['keys'][i], S)}"
+        seen.add(j)
+        assert dev_dump["sum_n"][i] == od["sum_n"][j]
+        assert (dev_dump["n"][i] == od["n"][j]).all()
+        assert (dev_dump["w"][i].view(np.uint32) == od["w"][j].view(np.uint32)).all()
+        assert (dev_dump["p"][i].view(np.uint32) == od["p"][j].view(np.uint32)).all()
+        assert (dev_dump["f32"][i] == od["f32"][j]).all()
+    if root_state is None:
+        assert len(seen) == len(omap)
+    return len(seen), len(omap)
+
+
+@pytest.mark.parametrize("S,goal,sims,upper,training,seed,salt,peak,random_a", [
+    (6, 4, 120, 160, True, 3, 1237, 16384, False),
+    (7, 4, 50, 70, True, 1, 1235, 4096, False),
+    (11, 5, 60, 80, True, 0, 1234, 0, False),
+    (11, 5, 300, 400, True, 5, 99, 8192, False),
+    (11, 5, 80, 100, False, 2, 1236, 8192, False),
+    (7, 4, 60, 80, False, 6, 78, 4096, True),
+    (15, 5, 40, 60, True, 8, 5, 8192, False),
+])
+def test_player_get_action_matches_oracle(S, goal, sims, upper, training, seed, salt, peak, random_a):
+    from alphafive_amd.player import Player
+    from alphafive_amd import utils
+    cfg = make_cfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper)
+    pl = Player(cfg, training=training, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak), seed=seed, game_id=7)
+    orc = oracle.OraclePlayer(cfg, training=training, rng_mode=oracle.RNG_PHILOX, seed=seed, game_id=7,
+                              pseudo_salt=salt, pseudo_peak=peak)
+    state, last, over, ply = pl.get_init_state(), None, False, 0
+    max_plies = 12 if S >= 11 else 60
+    while not over and ply < max_plies:
+        pol, act = pl.get_action(state, last_action=last, random_a=random_a)
+        opol, oact, ovis = orc.get_action(state, last, random_a)
+        assert (pl.last_visits == ovis).all(), f"ply {ply}: visit counts differ"
+        assert act == oact, f"ply {ply}"
+        if opol is None:
+            assert pol is None
+        else:
+            assert (pol.view(np.uint32) == opol.view(np.uint32)).all(), f"ply {ply}: policy bits differ"
+        assert pl.tau == orc.tau
+        board = utils.step(utils.state_to_board(state, S), act)
+        state = utils.board_to_state(board)
+        over, _ = utils.is_game_over(board, goal)
+        last, ply = act, ply + 1
+    _compare_tree(pl._engine.tree_dump(0), orc, S)
+    # the dict-like tree view mirrors player.py's State/Action objects
+    tv = pl.tree
+    assert len(tv) == orc.tree_size()
+    pl.close()
+
+
+def test_player_run_and_reset_match_oracle():
+    from alphafive_amd.player import Player
+    cfg = make_cfg(board_size=6, goal=4, simulation_per_step=60, upper_simulation_per_step=80)
+    salt, peak = 4242, 16384
+    pl = Player(cfg, training=True, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak), seed=11, game_id=0)
+    orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=11, game_id=0,
+                              pseudo_salt=salt, pseudo_peak=peak)
+    for _ in range(2):
+        rec = pl.run()
+        orec, _ = orc.run()
+        assert len(rec) == len(orec)
+        for (s, p, la, v, w), (os_, op, ola, ov, ow) in zip(rec, orec):
+            assert s == os_ and la == ola and v == ov and isinstance(v, float)
+            assert w == ow and isinstance(w, np.float32)
+            assert (p.view(np.uint32) == op.view(np.uint32)).all()
+        assert len(pl.tree) == 0
+    pl.close()
+
+
+@pytest.mark.parametrize("S,goal,sims,upper,G,node_cap", [
+    (6, 4, 60, 80, 64, 0),
+    (7, 4, 40, 60, 48, 0),
+    (6, 4, 60, 80, 16, 100),      # tight store: exercises the superset compaction every move
+])
+def test_selfplay_episodes_match_oracle(S, goal, sims, upper, G, node_cap):
+    import torch
+    from alphafive_amd.engine import SelfPlayEngine, assemble_episode
+    cfg = make_cfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper)
+    salt, peak, seed, first = 31337, 16384, 2024, 100
+    sp = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, salt, peak), device=0, seed=seed,
+                        first_game_id=first, node_cap=node_cap)
+    want = 2 * G
+    got = {}
+    for _ in range(400):
+        sp.run_ticks(64)
+        sp.check()
+        for raw in sp.pop_raw(cap=64):
+            got.setdefault(raw["game"], []).append(raw)
+        if sum(len(v) for v in got.values()) >= want and all(len(got.get(g, [])) >= 1 for g in range(G)):
+            break
+    assert all(len(got.get(g, [])) >= 1 for g in range(G)), "some games never finished"
+    checked = 0
+    for g in range(0, G, max(1, G // 12)):
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=seed, game_id=first + g,
+                                  pseudo_salt=salt, pseudo_peak=peak)
+        for raw in got[g]:
+            orec, extra = orc.run()
+            assert raw["T"] == len(orec), f"game {g} seq {raw['seq']}"
+            assert (raw["actions"] == extra["actions"]).all()
+            assert (raw["visits"] == extra["visits"]).all()
+            assert raw["final_value"] == extra["final_value"]
+            rec, result = assemble_episode(raw, S, cfg.gamma)
+            for (s, p, la, v, w), (os_, op, ola, ov, ow) in zip(rec, orec):
+                assert s == os_ and la == ola and v == ov and w == ow
+                assert (p.view(np.uint32) == op.view(np.uint32)).all()
+            checked += 1
+    assert checked >= 6
+    ct = sp.counters()
+    assert ct["episodes"] >= len(got)
+    sp.close()
+
+
+def test_engine_fails_loudly_on_full_store():
+    from alphafive_amd import engine as eng
+    import torch
+    cfg = make_cfg(board_size=6, goal=4, simulation_per_step=50, upper_simulation_per_step=60)
+    e = eng.Engine(cfg, 1, mode=eng.MODE_EXTERNAL, training=True, seed=1, node_cap=58)
+    planes = torch.zeros((1, 3, 6, 6), device="cuda")
+    policy = torch.full((1, 36), 1 / 36, device="cuda")
+    value = torch.zeros((1,), device="cuda")
+    e.set_root(0, eng.state_to_key("g/g/g/g/g/g/", 6))
+    with pytest.raises(eng.EngineError):
+        for _ in range(3):
+            # second move would need > 58 nodes even after compaction is impossible at the same root
+            for _ in range(200):
+                e.tick(policy.data_ptr(), value.data_ptr(), planes.data_ptr())
+            e.status()
+            e.set_root(0, eng.state_to_key("g/g/g/g/g/g/", 6))
+    e.close()
