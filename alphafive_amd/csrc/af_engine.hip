@@ -35,7 +35,7 @@
 typedef unsigned long long u64;
 
 enum { PH_IDLE = 0, PH_MOVE_START = 1, PH_SEARCH = 2, PH_MOVE_DONE = 3, PH_ERROR = 4 };
-enum { CT_SIMS = 0, CT_SELECTS, CT_EXPANDS, CT_TERMINALS, CT_PLIES, CT_EPISODES, CT_LSUM, CT_RESERVED, CT_N };
+enum { CT_SIMS = 0, CT_SELECTS, CT_EXPANDS, CT_TERMINALS, CT_PLIES, CT_EPISODES, CT_LSUM, CT_LEXP, CT_N };
 
 struct EngineParams {
     int G, S, C, goal, sims, upper, training, mode, node_cap, max_ply;
@@ -66,6 +66,7 @@ struct EngineParams {
     float* rec_policy;
     int32_t *rec_visits, *rec_last, *rec_action;
     u64* counters;
+    u64* progress;   // [0] plies committed, [1] episodes finished (all games)
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(64) void af_tick_kernel(EngineParams P, const float
             __syncthreads();
             backup(depth, rflf(value_in[g]), 1);
             ct[CT_EXPANDS]++;
+            ct[CT_LEXP] += (u64)bb_count<KW>(legal);
         }
         ct[CT_SIMS]++;
         sims_left--;
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(64) void af_tick_kernel(EngineParams P, const float
 #pragma unroll
             for (int k = 0; k < KW; ++k) pol[k] = 0.0f;
             ct[CT_PLIES]++;
+            if (lane == 0) atomicAdd(&P.progress[0], 1ull);
             if (!P.training && !random_a) {
                 has_policy = 0;                                                                  // :106-107
             } else {
@@ -538,6 +541,7 @@ __global__ __launch_bounds__(64) void af_tick_kernel(EngineParams P, const float
                     P.ep_seq[g] = seq + 1u;
                 }
                 ct[CT_EPISODES]++;
+                if (lane == 0) atomicAdd(&P.progress[1], 1ull);
                 for (uint32_t s_ = lane; s_ <= P.hash_mask; s_ += 64) slots[s_] = 0;
                 __syncthreads();
                 nodes = 0;
@@ -784,7 +788,7 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     A(episode, G); A(sel, G); A(plyctr, G); A(path_node, G * CP); A(path_cell, G * CP);
     A(hash, G * hcap); A(node_key, G * node_cap * 2 * KW); A(node_sum, G * node_cap);
     A(edge_n, G * node_cap * CP); A(edge_w, G * node_cap * CP); A(edge_p, G * node_cap * CP);
-    A(ep_seq, G); A(ep_popped, G); A(counters, G * CT_N);
+    A(ep_seq, G); A(ep_popped, G); A(counters, G * CT_N); A(progress, 2);
     if (mode == AF_MODE_SELFPLAY) {
         const size_t R = G * 2 * P.max_ply;
         A(ep_len, G * 2); A(ep_final, G * 2); A(rec_key, R * 2 * KW); A(rec_policy, R * C); A(rec_visits, R * C);
@@ -931,11 +935,19 @@ int af_engine_counters(af_engine* e, void* stream, uint64_t* out) {
     HIP_OK(hipMemcpyAsync(e->h_ct.data(), e->P.counters, (size_t)G * CT_N * 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(e->h_i32.data(), e->P.nodes, (size_t)G * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    for (int i = 0; i < CT_N; ++i) out[i] = 0;
+    for (int i = 0; i <= CT_N; ++i) out[i] = 0;
     for (int g = 0; g < G; ++g) {
         for (int i = 0; i < CT_N; ++i) out[i] += e->h_ct[(size_t)g * CT_N + i];
-        out[7] += (uint64_t)e->h_i32[g];
+        out[CT_N] += (uint64_t)e->h_i32[g];
     }
+    return AF_OK;
+}
+
+int af_engine_progress(af_engine* e, void* stream, uint64_t* out) {
+    if (!e || !out) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemcpyAsync(out, e->P.progress, 16, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
     return AF_OK;
 }
 

@@ -68,6 +68,7 @@ def lib():
         L.af_engine_set_training.argtypes = [vp, C.c_int32]
         L.af_engine_pop_episodes.argtypes = [vp, vp, C.c_int32, i32p, f32p, u64p, f32p, i32p, i32p, i32p]
         L.af_engine_counters.argtypes = [vp, vp, u64p]
+        L.af_engine_progress.argtypes = [vp, vp, u64p]
         L.af_engine_tree_dump.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
         L.af_state_to_key.argtypes = [C.c_char_p, C.c_int32, u64p]
         L.af_key_to_state.argtypes = [u64p, C.c_int32, C.c_char_p, C.c_int32]
@@ -102,7 +103,8 @@ def key_to_state(key, S):
     return out.value.decode()
 
 
-COUNTER_NAMES = ("sims", "selects", "expands", "terminals", "plies", "episodes", "legal_sum", "nodes")
+COUNTER_NAMES = ("sims", "selects", "expands", "terminals", "plies", "episodes", "legal_sum", "legal_sum_expand",
+                 "nodes")
 
 
 class Engine:
@@ -157,9 +159,14 @@ class Engine:
         return a.value, (pol if hp.value else None), vis, tau.value
 
     def counters(self, stream=None):
-        out = np.zeros(8, np.uint64)
+        out = np.zeros(9, np.uint64)
         _check(lib().af_engine_counters(self._h, stream, _p(out, C.c_uint64)), "af_engine_counters")
         return {k: int(v) for k, v in zip(COUNTER_NAMES, out)}
+
+    def progress(self, stream=None):
+        out = np.zeros(2, np.uint64)
+        _check(lib().af_engine_progress(self._h, stream, _p(out, C.c_uint64)), "af_engine_progress")
+        return int(out[0]), int(out[1])
 
     def tree_dump(self, game):
         cnt = _check(lib().af_engine_tree_dump(self._h, game, 0, None, None, None, None, None, None), "tree_dump")
@@ -270,6 +277,9 @@ class SelfPlayEngine:
 
     def counters(self):
         return self.engine.counters(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def progress(self):
+        return self.engine.progress(self.torch.cuda.current_stream(self.dev).cuda_stream)
 
     def pop_raw(self, cap=256):
         return self.engine.pop_episodes_raw(cap, self.torch.cuda.current_stream(self.dev).cuda_stream)

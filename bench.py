@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py — self-play moves/sec (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 4 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: 4096 concurrent 11x11 games per GPU, 500 sims/move
+(cap 642), training-mode search (Dirichlet noise, forced root visits, temperature play),
+alphaFive-6960 weights, fp32 net, batched leaf evaluation.  Weak scaling: every rank owns
+its own 4096 games (game id = rank*4096 + g), no collective on the tick path; finished
+episodes are gathered to rank 0 over RCCL at step boundaries.
+
+A "step" = one pass of the hot path over the batch that commits one move per game on
+average: the rank ticks (tree kernel -> leaf batch -> net) until its games have committed
+G more plies (~460-500 ticks).  value = plies committed by all ranks in the timed region /
+max-over-ranks wall time.  Inputs are synthetic (all games start from the empty board) and
+resident in HBM; nothing crosses PCIe on the tick path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_POSITION = 118_727_264          # SURVEY §2.2 (59,363,632 MAC) at S=11
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def make_cfg(sims=500, upper=642, board=11):
+    return types.SimpleNamespace(board_size=board, goal=5, simulation_per_step=sims, upper_simulation_per_step=upper,
+                                 init_temp=1.2, gamma=0.94, tau_decay_rate=0.94, tau_decay_rate_r=0.9,
+                                 dirichlet_alpha=0.3, c_puct=5.0)
+
+
+def tree_bytes(ct, C):
+    """SURVEY §8d algorithmic bytes: per select 12L+40 (+16 backup), per expand 4L+32+16C+4, per sim R."""
+    R = 128 if C <= 128 else 256
+    return (12 * ct["legal_sum"] + 56 * ct["selects"] + 4 * ct["legal_sum_expand"]
+            + (32 + 16 * C + 4) * ct["expands"] + R * ct["sims"])
+
+
+def cpu_baseline(cfg, weights, budget_s=20.0):
+    """The C oracle (oracle/af_oracle.c, "port") + torch-CPU fp32 net on ONE host core: the same
+    config-2 search for one game, first plies until the time budget is spent."""
+    import torch
+    import oracle
+    from alphafive_amd.network import ResNet
+    torch.set_num_threads(1)
+    net = ResNet(cfg.board_size, device="cpu")
+    net.load_npz(weights)
+    pl = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=0, game_id=0, pv_fn=net.eval)
+    board = np.zeros((cfg.board_size, cfg.board_size), np.int8)
+    state, last, plies = oracle.board_to_state(board), None, 0
+    t0 = time.time()
+    while time.time() - t0 < budget_s:
+        _, act, _ = pl.get_action(state, last)
+        board = oracle.step(oracle.state_to_board(state, cfg.board_size), act)
+        state, last, plies = oracle.board_to_state(board), act, plies + 1
+        if oracle.is_game_over(board, cfg.goal)[0]:
+            break
+    dt = time.time() - t0
+    st = pl.stats()
+    pl.close()
+    return {"value": plies / dt, "unit": "moves/s", "cores": 1, "kind": "port",
+            "sample": f"1 game, first {plies} plies of config 2 (11x11, {cfg.simulation_per_step} sims/move, "
+                      f"training mode), C oracle + torch-CPU fp32 net, 1 thread, {dt:.1f} s, "
+                      f"{st['sims']} sims / {st['expands']} net evals"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=500)
+    ap.add_argument("--upper", type=int, default=642)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--net", default="auto", choices=["auto", "torch", "hip"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.network import ResNet
+    from alphafive_amd import dist as afdist
+
+    cfg = make_cfg(args.sims, args.upper)
+    G, C = args.games, cfg.board_size ** 2
+    weights = os.path.join(REPO, "tests", "golden", "alphaFive-6960.weights.npz")
+    net = ResNet(cfg.board_size, device=dev)
+    net.load_npz(weights)
+    if world > 1:
+        afdist.broadcast_weights(net, src=0)      # one 3 MB broadcast, as a weight update would do
+    pv = net.select_backend(args.net)
+    sp = SelfPlayEngine(cfg, G, pv, device=local, seed=args.seed, first_game_id=rank * G)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    ev_tick, ev_net = [], []
+    timing = {"on": False}
+    gathered = {"episodes": 0, "plies": 0}
+
+    def one_tick():
+        if timing["on"]:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            sp.engine.tick(sp.policy.data_ptr(), sp.value.data_ptr(), sp.planes.data_ptr(), stream)
+            e1.record()
+            p, v = pv(sp.planes)
+            if p.data_ptr() != sp.policy.data_ptr():
+                sp.policy.copy_(p)
+                sp.value.copy_(v)
+            e2.record()
+            ev_tick.append((e0, e1))
+            ev_net.append((e1, e2))
+        else:
+            sp.tick()
+
+    def run_step(target):
+        while True:
+            for _ in range(args.poll):
+                one_tick()
+            plies, _ = sp.progress()
+            if plies >= target:
+                break
+        sp.check()
+        # finished episodes -> rank 0 (RCCL gather over xGMI when world > 1)
+        eps = afdist.gather_episodes(sp.pop_raw(cap=1024), world, rank, dev)
+        if rank == 0:
+            gathered["episodes"] += len(eps)
+            gathered["plies"] += sum(e["T"] for e in eps)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    target = 0
+    for _ in range(args.warmup):
+        target += G
+        run_step(target)
+    barrier()
+    ct0 = sp.counters()
+    p0 = sp.progress()[0]
+    timing["on"] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        target += G
+        run_step(target)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing["on"] = False
+    ct1 = sp.counters()
+    plies = sp.progress()[0] - p0
+
+    tot = torch.tensor([float(plies)], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_plies, t = float(tot.item()), float(tmax.item())
+
+    if rank == 0:
+        d = {k: ct1[k] - ct0[k] for k in ct1}
+        n_ticks = len(ev_tick)
+        tick_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_tick]))
+        net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net]))
+        net_tflops = G * FLOP_PER_POSITION / (net_ms * 1e-3) / 1e12
+        tree_gbs = tree_bytes(d, C) / n_ticks / (tick_ms * 1e-3) / 1e9
+        roof = net.roofline_info(pv)
+        out = {
+            "metric": "self-play moves/sec (11x11, 500 sims/move)", "value": total_plies / t, "unit": "moves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {G} concurrent 11x11 games per GPU, {args.sims} sims/move "
+                                   f"(cap {args.upper}), training-mode MCTS, alphaFive-6960 net fp32, batched leaf eval",
+                       "games_per_gpu": G, "sims_per_move": args.sims, "net_backend": roof["backend"],
+                       "step": "ticks until the batch commits G more plies", "ticks_timed_rank0": n_ticks,
+                       "sims_per_ply_rank0": d["sims"] / max(1, d["plies"]),
+                       "selects_per_sim": d["selects"] / max(1, d["sims"]),
+                       "terminal_frac": d["terminals"] / max(1, d["sims"]),
+                       "episodes_gathered": gathered["episodes"]},
+            "roofline": {"kernel": roof["kernel"], "bound": "mfma", "achieved": net_tflops,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": net_tflops / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "ms_per_launch": net_ms,
+                         "flop_per_launch": G * FLOP_PER_POSITION},
+            "tree_roofline": {"kernel": "af_tick_kernel<2>", "bound": "hbm", "achieved": tree_gbs,
+                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": None,
+                              "ms_per_launch": tick_ms, "bytes_per_launch": tree_bytes(d, C) / n_ticks},
+            "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, weights)
+        print(json.dumps(out), flush=True)
+    sp.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

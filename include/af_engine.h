@@ -111,9 +111,12 @@ int af_engine_set_training(af_engine* e, int32_t training);
 int af_engine_pop_episodes(af_engine* e, void* stream, int32_t cap, int32_t* meta, float* final_value,
                            uint64_t* keys, float* policies, int32_t* visits, int32_t* lasts, int32_t* actions);
 
-/* counters summed over games: out[0..7] = sims, selects, expands, terminal hits, plies,
- * episodes, sum of L over selects, nodes currently stored */
+/* counters summed over games: out[0..8] = sims, selects, expands, terminal hits, plies,
+ * episodes, sum of L over selects, sum of L over expands, nodes currently stored */
 int af_engine_counters(af_engine* e, void* stream, uint64_t* out);
+
+/* cheap progress poll (16-byte copy): out[0] = plies committed, out[1] = episodes finished */
+int af_engine_progress(af_engine* e, void* stream, uint64_t* out);
 
 /* tree inspection (tests / Player.tree): nodes of game g in storage order.
  * n has the "w is fp32-typed" flag stripped into f32[]. Returns node count or <0. */
