@@ -1,0 +1,72 @@
+"""N>1 path on CPU: world_size-2 gloo run of the episode gather, weight broadcast and move counter."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from alphafive_amd import dist as afdist
+
+
+def _episode(rank, i, T, C=36, kw2=4):
+    rng = np.random.RandomState(rank * 100 + i)
+    return dict(game=i, seq=i % 3, T=T, final_value=-1.0 if i % 2 else 0.0,
+                keys=rng.randint(0, 2 ** 62, size=(T, kw2)).astype(np.uint64),
+                policies=rng.rand(T, C).astype(np.float32), visits=rng.randint(0, 500, size=(T, C)).astype(np.int32),
+                lasts=rng.randint(-1, C, size=T).astype(np.int32), actions=rng.randint(0, C, size=T).astype(np.int32))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    mine = [_episode(rank, i, 5 + 3 * i + rank) for i in range(2 + rank)]
+    got = afdist.gather_episodes(mine, world, rank, dev, game_offset=rank * 1000)
+    total = afdist.all_reduce_sum(sum(e["T"] for e in mine), dev)
+    from alphafive_amd.network import ResNet
+    net = ResNet(6, device="cpu", seed=rank)          # different weights per rank before the broadcast
+    afdist.broadcast_weights(net, src=0)
+    digest = float(sum(np.abs(v).sum() for v in net.variables.values()))
+    q.put((rank, [(e["game"], e["seq"], e["T"], e["final_value"], float(e["policies"].sum()),
+                   int(e["visits"].sum()), int(e["keys"].sum() % 1000003)) for e in got], total, digest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gather_broadcast_allreduce():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=120)
+        res[r[0]] = r
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    expect = []
+    for rank in range(2):
+        for i in range(2 + rank):
+            e = _episode(rank, i, 5 + 3 * i + rank)
+            expect.append((e["game"] + rank * 1000, e["seq"], e["T"], e["final_value"], float(e["policies"].sum()),
+                           int(e["visits"].sum()), int(e["keys"].sum() % 1000003)))
+    assert sorted(res[0][1]) == sorted(expect)          # rank 0 holds everyone's episodes, bit-exact
+    assert res[1][1] == []
+    assert res[0][2] == res[1][2] == sum(t[2] for t in expect)
+    assert res[0][3] == res[1][3]                       # identical weights after the broadcast
+
+
+def test_pack_unpack_roundtrip_empty_and_ragged():
+    assert afdist.unpack_episodes(afdist.pack_episodes([])) == []
+    eps = [_episode(0, i, T) for i, T in enumerate([1, 9, 36])]
+    back = afdist.unpack_episodes(afdist.pack_episodes(eps))
+    for a, b in zip(eps, back):
+        assert a["game"] == b["game"] and a["T"] == b["T"] and a["final_value"] == b["final_value"]
+        for k in ("keys", "policies", "visits", "lasts", "actions"):
+            assert (a[k] == b[k]).all()

@@ -56,7 +56,7 @@ MCTS = sorted(glob.glob(os.path.join(GOLDEN, "mcts_*.npz")))
 
 @pytest.mark.parametrize("path", MCTS, ids=[os.path.basename(p) for p in MCTS])
 def test_mcts_trace_bit_exact(path):
-    z = np.load(path)
+    z = dict(np.load(path))
     cfg = cfg_from_golden(z)
     S = cfg.board_size
     pl = oracle.OraclePlayer(cfg, training=bool(z["training"]), rng_mode=oracle.RNG_MT, seed=int(z["seed"]),
@@ -98,7 +98,7 @@ RUNS = sorted(glob.glob(os.path.join(GOLDEN, "run_*.npz")))
 
 @pytest.mark.parametrize("path", RUNS, ids=[os.path.basename(p) for p in RUNS])
 def test_run_episode_records(path):
-    z = np.load(path)
+    z = dict(np.load(path))
     cfg = cfg_from_golden(z)
     S = cfg.board_size
     pl = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_MT, seed=int(z["seed"]),
