@@ -17,6 +17,7 @@ HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared"
 # exactly as written; the net kernels are free to contract (fp32 MFMA is an fma chain).
 TARGETS = {
     "libaf_hip.so": (["csrc/af_engine.hip"], ["-ffp-contract=off"]),
+    "libaf_net.so": (["csrc/af_net.hip"], []),
 }
 
 

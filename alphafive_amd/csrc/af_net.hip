@@ -1,0 +1,571 @@
+// af_net.hip — hand-written gfx950 forward pass of the alphaFive policy/value net
+// (genData/network.py:52-97,163-165) in fp32 on the matrix cores.
+//
+// Every 3x3 convolution (97 % of the FLOPs) and the 1x1 projection of each residual block run in
+// ONE implicit-GEMM kernel, af_conv_mfma<NT,MT>:   D[cout][pixel] = sum_k W[k][cout] * X[k][pixel]
+//   * v_mfma_f32_32x32x2_f32: A operand = 32 couts x 2 k (weights), B operand = 2 k x 32 pixels
+//     (activations), 16 accumulator registers per 32x32 tile; exact fp32 (an fmaf chain in k order).
+//   * k runs over (cin pair, tap): a tap is a constant address shift in the zero-padded plane
+//     layout [b][c][(S+2)*(S+2) (+pad)], so the B fragment is one global_load_dword per lane with
+//     32 consecutive pixels per k — no im2col, no LDS staging (fp32 MFMA needs only 2 operand
+//     dwords per 64-cycle instruction; operands come straight from L1/L2 with register reuse:
+//     each weight fragment feeds MT pixel tiles, each activation fragment feeds NT cout tiles).
+//   * weights are pre-packed k-pair-major ([cin/2][tap][2][cout]) so every wave streams them
+//     linearly; the block's 1x1 projection is appended to the k loop as a second segment;
+//     bias, residual add and ELU are fused in the epilogue, which writes straight into the next
+//     layer's padded layout (rows of the D tile are couts, so stores are pixel-contiguous).
+//   * pixel tiles run over the flattened batch (row = b*S*S + pixel): no per-position padding
+//     waste; one wave owns MT pixel tiles x all couts (NT*MT*16 <= 128 accumulator VGPRs).
+// The 5x5 stem (0.25 % of FLOPs) and the two heads (1x1 conv + dense + tanh / softmax, 0.6 %)
+// are small VALU kernels.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "af_net.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvSeg {
+    const float* in;   // [batch][cin][PP]
+    const float* w;    // packed [cin/2][taps][2][cout_pad]
+    int cin, taps;
+};
+struct ConvArgs {
+    ConvSeg seg[2];
+    int nseg;
+    const float* bias;   // [cout_pad]
+    float* out;          // [batch][cout][PP]
+    int cout, cout_pad, rows, S, HW, WP, PP, elu;
+};
+
+// ELU(alpha=1).  exp(x)-1 through the hardware exp2 (absolute error ~1e-7 at x -> 0-, far inside the
+// 1e-5 parity budget); expm1f costs ~30 VALU ops per element and sat un-overlapped in the epilogue.
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+
+// One lane's weight fragments for NT cout tiles are NT consecutive floats (cout = col*NT + nt):
+// a single dword / dwordx2 / dwordx4 load.
+template <int NT>
+__device__ __forceinline__ void load_wfrag(const float* __restrict__ p, float (&a)[NT]) {
+    if constexpr (NT == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    } else if constexpr (NT == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        a[0] = v.x; a[1] = v.y;
+    } else {
+        a[0] = p[0];
+    }
+}
+
+// k loop of one segment, software-pipelined by hand: k-steps are processed in groups of GS
+// (all 9 taps of one cin pair for 3x3, 8 channel pairs for 1x1); the operands of group g+1 are
+// loaded into a second register set before the MFMAs of group g issue, so every load has
+// GS*NT*MT*64 MFMA cycles (4608 for the 128-wide layers, ~2 us) to land.  sched_barrier keeps
+// hipcc from sinking the loads next to their uses (its own schedule prefetched < 1 k-step ahead:
+// 64.7 TFLOP/s; 3-tap groups 79.6; 9-tap groups 88.4 — profiles/r1_02_*).  One wave per SIMD
+// (accumulators in AGPRs, operand sets in VGPRs): the 2-waves/SIMD builds spill under hipcc's
+// 16-register-tuple allocation and measured slower.
+template <int NT, int MT, int TAPS>
+__device__ __forceinline__ void conv_segment(const ConvSeg& sg, const int* __restrict__ base, int kh, int col, int cout_pad,
+                                             int WP, int PP, f32x16 (&acc)[NT][MT]) {
+    constexpr int GS = TAPS == 9 ? 9 : 8;
+    // addressing = wave-uniform 64-bit base (SGPR pair, advanced per group) + one 32-bit per-lane
+    // byte offset (VGPR) + immediate: keeps the load address state at MT+1 VGPRs
+    const char* __restrict__ inb = reinterpret_cast<const char*>(sg.in);
+    const char* __restrict__ wbb = reinterpret_cast<const char*>(sg.w);
+    const uint32_t woff = (uint32_t)(kh * cout_pad + col * NT) * 4u;
+    uint32_t boff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) boff[mt] = (uint32_t)(base[mt] + kh * PP) * 4u;
+    const int ngroups = (sg.cin / 2) * TAPS / GS;          // even for every layer of this net
+    float a0[GS][NT], b0[GS][MT], a1[GS][NT], b1[GS][MT];
+
+    auto load_group = [&](int g, float (&a)[GS][NT], float (&b)[GS][MT]) {
+        const char* ig;
+        if constexpr (TAPS == 9) ig = inb + (ptrdiff_t)(2 * g) * PP * 4;        // group = all 9 taps of one cin pair
+        else ig = inb + (ptrdiff_t)(2 * g * GS) * PP * 4;                       // group = 8 cin pairs
+        const char* wg = wbb + (size_t)(g * GS) * 2 * cout_pad * 4;             // uniform
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            const ptrdiff_t joff = TAPS == 9 ? (ptrdiff_t)((j / 3 - 1) * WP + (j % 3 - 1)) * 4 : (ptrdiff_t)(2 * j) * PP * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                b[j][mt] = *reinterpret_cast<const float*>(ig + joff + (size_t)boff[mt]);
+            load_wfrag<NT>(reinterpret_cast<const float*>(wg + (size_t)j * 2 * cout_pad * 4 + (size_t)woff), a[j]);
+        }
+    };
+    auto compute = [&](float (&a)[GS][NT], float (&b)[GS][MT]) {
+#pragma unroll
+        for (int j = 0; j < GS; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][nt], b[j][mt], acc[nt][mt], 0, 0, 0);
+    };
+
+    // (measured r1: an extra "touch" load of the next-but-one cin pair's planes, to give first-touch
+    // L2 misses two phases to land, changed nothing: 5.51 vs 5.50 ms — the remaining s_waitcnt time
+    // is not first-touch latency.)
+    load_group(0, a0, b0);
+    for (int g = 0; g < ngroups; g += 2) {
+        load_group(g + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < ngroups) load_group(g + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NT, int MT, int MINW>
+__global__ __launch_bounds__(256, MINW) void af_conv_mfma(ConvArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int tile0 = task * MT;
+    if (tile0 * 32 >= A.rows) return;
+    int pos[MT], poff[MT];
+    bool valid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = (tile0 + mt) * 32 + col;
+        valid[mt] = row < A.rows;
+        const int r = valid[mt] ? row : 0;
+        pos[mt] = r / A.HW;
+        const int pix = r - pos[mt] * A.HW;
+        const int y = pix / A.S;
+        poff[mt] = (y + 1) * A.WP + (pix - y * A.S) + 1;
+    }
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
+
+    for (int s = 0; s < A.nseg; ++s) {
+        const ConvSeg sg = A.seg[s];
+        int base[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) base[mt] = pos[mt] * sg.cin * A.PP + poff[mt];
+        if (sg.taps == 9) conv_segment<NT, MT, 9>(sg, base, kh, col, A.cout_pad, A.WP, A.PP, acc);
+        else conv_segment<NT, MT, 1>(sg, base, kh, col, A.cout_pad, A.WP, A.PP, acc);
+    }
+
+    // epilogue: D row = cout, D column = pixel  (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = ((r & 3) + 8 * (r >> 2) + 4 * kh) * NT + nt;   // tile nt, D row i <-> cout i*NT + nt
+            const float bv = A.bias[co];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float v = acc[nt][mt][r] + bv;
+                if (A.elu) v = elu1(v);
+                if (valid[mt] && co < A.cout) A.out[(size_t)(pos[mt] * A.cout + co) * A.PP + poff[mt]] = v;
+            }
+        }
+    }
+}
+
+// stem: conv 5x5 SAME 3->32 + ELU (network.py:63), one block per position, one thread per pixel
+__global__ __launch_bounds__(256) void af_stem_conv(const float* __restrict__ planes, const float* __restrict__ w /*[75][32]*/,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int S, int WP, int PP) {
+    __shared__ float sx[3 * 20 * 20];
+    __shared__ float sw[75 * 32];
+    __shared__ float sb[32];
+    const int b = blockIdx.x, t = threadIdx.x, HW = S * S, XP = S + 4;
+    for (int i = t; i < 3 * XP * XP; i += blockDim.x) sx[i] = 0.0f;
+    for (int i = t; i < 75 * 32; i += blockDim.x) sw[i] = w[i];
+    if (t < 32) sb[t] = bias[t];
+    __syncthreads();
+    for (int i = t; i < 3 * HW; i += blockDim.x) {
+        const int c = i / HW, p = i - c * HW, y = p / S, x = p - y * S;
+        sx[c * XP * XP + (y + 2) * XP + x + 2] = planes[(size_t)b * 3 * HW + i];
+    }
+    __syncthreads();
+    if (t >= HW) return;
+    const int y = t / S, x = t - y * S;
+    float acc[32];
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[co] = sb[co];
+    for (int ky = 0; ky < 5; ++ky)
+        for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float xv = sx[c * XP * XP + (y + ky) * XP + x + kx];
+                const float* wr = sw + ((ky * 5 + kx) * 3 + c) * 32;
+#pragma unroll
+                for (int co = 0; co < 32; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+            }
+    float* o = out + (size_t)b * 32 * PP + (y + 1) * WP + x + 1;
+#pragma unroll
+    for (int co = 0; co < 32; ++co) o[(size_t)co * PP] = elu1(acc[co]);
+}
+
+// value head: 1x1 conv 32->4 + ELU, fc 4*HW->64 + ELU, fc 64->1, tanh(x/2)  (network.py:70-76,163)
+__global__ __launch_bounds__(256) void af_value_head(const float* __restrict__ in /*[b][32][PP]*/, const float* __restrict__ wc /*[32][4]*/,
+                                                     const float* __restrict__ bc, const float* __restrict__ w1 /*[4HW][64]*/,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2 /*[64]*/,
+                                                     const float* __restrict__ b2, float* __restrict__ value, int S, int WP, int PP) {
+    __shared__ float sh[4 * 256];
+    __shared__ float swc[32 * 4];
+    __shared__ float s64[64];
+    const int b = blockIdx.x, t = threadIdx.x, HW = S * S;
+    if (t < 128) swc[t] = wc[t];
+    __syncthreads();
+    if (t < HW) {
+        const int y = t / S, x = t - y * S;
+        const float* p = in + (size_t)b * 32 * PP + (y + 1) * WP + x + 1;
+        float a0 = bc[0], a1 = bc[1], a2 = bc[2], a3 = bc[3];
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) {
+            const float xv = p[(size_t)c * PP];
+            a0 = fmaf(xv, swc[c * 4 + 0], a0); a1 = fmaf(xv, swc[c * 4 + 1], a1);
+            a2 = fmaf(xv, swc[c * 4 + 2], a2); a3 = fmaf(xv, swc[c * 4 + 3], a3);
+        }
+        sh[0 * HW + t] = elu1(a0); sh[1 * HW + t] = elu1(a1); sh[2 * HW + t] = elu1(a2); sh[3 * HW + t] = elu1(a3);
+    }
+    __syncthreads();
+    if (t < 64) {
+        float acc = b1[t];
+        for (int k = 0; k < 4 * HW; ++k) acc = fmaf(sh[k], w1[(size_t)k * 64 + t], acc);
+        s64[t] = elu1(acc) * w2[t];
+    }
+    __syncthreads();
+    if (t == 0) {
+        float s = b2[0];
+        for (int j = 0; j < 64; ++j) s += s64[j];
+        value[b] = tanhf(s * 0.5f);
+    }
+}
+
+// policy head: 1x1 conv 32->16 + ELU, fc 16*HW->HW, softmax  (network.py:82-88); PPB positions per block
+template <int PPB>
+__global__ __launch_bounds__(256) void af_policy_head(const float* __restrict__ in /*[b][32][PP]*/, const float* __restrict__ wc /*[32][16]*/,
+                                                      const float* __restrict__ bc, const float* __restrict__ wf /*[16HW][HW]*/,
+                                                      const float* __restrict__ bf, float* __restrict__ policy, int batch, int S, int WP, int PP) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = S * S, t = threadIdx.x, b0 = blockIdx.x * PPB;
+    float* sh = smem;                       // [16*HW][PPB]
+    float* swc = smem + 16 * HW * PPB;      // [32][16]
+    float* red = swc + 512;                 // [4 waves][PPB]
+    for (int i = t; i < 512; i += blockDim.x) swc[i] = wc[i];
+    __syncthreads();
+    if (t < HW) {
+        const int y = t / S, x = t - y * S;
+        for (int p = 0; p < PPB; ++p) {
+            const int b = b0 + p < batch ? b0 + p : batch - 1;
+            const float* src = in + (size_t)b * 32 * PP + (y + 1) * WP + x + 1;
+            float a[16];
+#pragma unroll
+            for (int co = 0; co < 16; ++co) a[co] = bc[co];
+            for (int c = 0; c < 32; ++c) {
+                const float xv = src[(size_t)c * PP];
+#pragma unroll
+                for (int co = 0; co < 16; ++co) a[co] = fmaf(xv, swc[c * 16 + co], a[co]);
+            }
+#pragma unroll
+            for (int co = 0; co < 16; ++co) sh[(co * HW + t) * PPB + p] = elu1(a[co]);
+        }
+    }
+    __syncthreads();
+    float acc[PPB];
+    const int j = t < HW ? t : HW - 1;
+#pragma unroll
+    for (int p = 0; p < PPB; ++p) acc[p] = bf[j];
+    for (int k = 0; k < 16 * HW; ++k) {
+        const float wv = wf[(size_t)k * HW + j];
+        const float4* xr = reinterpret_cast<const float4*>(sh + (size_t)k * PPB);
+#pragma unroll
+        for (int q = 0; q < PPB / 4; ++q) {
+            const float4 xv = xr[q];
+            acc[4 * q + 0] = fmaf(xv.x, wv, acc[4 * q + 0]); acc[4 * q + 1] = fmaf(xv.y, wv, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(xv.z, wv, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(xv.w, wv, acc[4 * q + 3]);
+        }
+    }
+    // softmax over the HW logits of each position
+    const int wave = t >> 6, lane = t & 63, nw = blockDim.x >> 6;
+    float m[PPB];
+#pragma unroll
+    for (int p = 0; p < PPB; ++p) {
+        float v = t < HW ? acc[p] : -3.0e38f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if (lane == 0) red[wave * PPB + p] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PPB; ++p) {
+        float v = red[p];
+        for (int w_ = 1; w_ < nw; ++w_) v = fmaxf(v, red[w_ * PPB + p]);
+        m[p] = v;
+    }
+    __syncthreads();
+    float e[PPB];
+#pragma unroll
+    for (int p = 0; p < PPB; ++p) {
+        e[p] = t < HW ? expf(acc[p] - m[p]) : 0.0f;
+        float v = e[p];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+        if (lane == 0) red[wave * PPB + p] = v;
+    }
+    __syncthreads();
+    if (t < HW) {
+#pragma unroll
+        for (int p = 0; p < PPB; ++p) {
+            float s = red[p];
+            for (int w_ = 1; w_ < nw; ++w_) s += red[w_ * PPB + p];
+            if (b0 + p < batch) policy[(size_t)(b0 + p) * HW + t] = e[p] / s;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------
+#define NET_HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[af_net] %s failed: %s\n", #x, hipGetErrorString(e_)); return AF_NET_ERR_HIP; } } while (0)
+
+struct Block { const char* name; int cin, cout; };
+static const Block kBlocks[5] = {{"bone/block1", 32, 64}, {"bone/block2", 64, 128}, {"value/block3", 128, 32},
+                                 {"policy/block4", 128, 64}, {"policy/block5", 64, 32}};
+
+struct af_net {
+    int S, HW, WP, PP, max_batch, device;
+    bool ready = false;
+    std::map<std::string, std::vector<float>> vars;
+    std::map<std::string, size_t> expect;
+    std::vector<void*> allocs;
+    // device weights
+    float *stem_w, *stem_b;
+    float *conv1_w[5], *conv1_b[5], *conv2_w[5], *res_w[5], *sum_b[5];
+    float *vc_w, *vc_b, *v1_w, *v1_b, *v2_w, *v2_b, *pc_w, *pc_b, *pf_w, *pf_b;
+    // activations [max_batch][C][PP]
+    float *f0, *g[5], *o[5];
+};
+
+static int pad32(int c) { return (c + 31) / 32 * 32; }
+
+template <typename T>
+static int net_alloc(af_net* n, T** p, size_t count, bool zero) {
+    void* q = nullptr;
+    NET_HIP_OK(hipMalloc(&q, count * sizeof(T)));
+    if (zero) NET_HIP_OK(hipMemset(q, 0, count * sizeof(T)));
+    n->allocs.push_back(q);
+    *p = (T*)q;
+    return AF_NET_OK;
+}
+static int net_upload(af_net* n, float** p, const std::vector<float>& h) {
+    int rc = net_alloc(n, p, h.size(), false);
+    if (rc) return rc;
+    NET_HIP_OK(hipMemcpy(*p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    return AF_NET_OK;
+}
+
+// HWIO [taps][cin][cout] -> k-pair-major stream [cin/2][taps][2][cout_pad]
+static std::vector<float> pack_conv(const std::vector<float>& w, int taps, int cin, int cout) {
+    const int cp = pad32(cout);
+    std::vector<float> out((size_t)cin * taps * cp, 0.0f);
+    for (int c = 0; c < cin; ++c)
+        for (int t = 0; t < taps; ++t)
+            for (int co = 0; co < cout; ++co)
+                out[((((size_t)(c / 2) * taps + t) * 2) + (c & 1)) * cp + co] = w[((size_t)t * cin + c) * cout + co];
+    return out;
+}
+static std::vector<float> pad_bias(const std::vector<float>& a, const std::vector<float>* b, int cout) {
+    std::vector<float> out(pad32(cout), 0.0f);
+    for (int i = 0; i < cout; ++i) out[i] = a[i] + (b ? (*b)[i] : 0.0f);
+    return out;
+}
+
+extern "C" {
+
+const char* af_net_strerror(int code) {
+    switch (code) {
+        case AF_NET_OK: return "ok";
+        case AF_NET_ERR_ARG: return "bad argument";
+        case AF_NET_ERR_HIP: return "HIP runtime error";
+        case AF_NET_ERR_NAME: return "unknown variable name or wrong element count";
+        case AF_NET_ERR_STATE: return "network not finalized or variables missing";
+        default: return "unknown error";
+    }
+}
+
+int af_net_create(int32_t S, int32_t max_batch, int32_t device, af_net** out) {
+    if (!out || S < 3 || S > 16 || max_batch < 1) return AF_NET_ERR_ARG;
+    NET_HIP_OK(hipSetDevice(device));
+    af_net* n = new af_net();
+    n->S = S; n->HW = S * S; n->WP = S + 2; n->PP = ((S + 2) * (S + 2) + 15) / 16 * 16;
+    n->max_batch = max_batch; n->device = device;
+    const size_t HW = n->HW;
+    n->expect["bone/conv1/kernel"] = 75 * 32; n->expect["bone/conv1/bias"] = 32;
+    for (const Block& b : kBlocks) {
+        const std::string s = b.name;
+        n->expect[s + "_res/kernel"] = (size_t)b.cin * b.cout; n->expect[s + "_res/bias"] = b.cout;
+        n->expect[s + "_conv1/kernel"] = (size_t)9 * b.cin * b.cout; n->expect[s + "_conv1/bias"] = b.cout;
+        n->expect[s + "_conv2/kernel"] = (size_t)9 * b.cout * b.cout; n->expect[s + "_conv2/bias"] = b.cout;
+    }
+    n->expect["value/conv/kernel"] = 32 * 4; n->expect["value/conv/bias"] = 4;
+    n->expect["value/fc1/kernel"] = 4 * HW * 64; n->expect["value/fc1/bias"] = 64;
+    n->expect["value/fc2/kernel"] = 64; n->expect["value/fc2/bias"] = 1;
+    n->expect["policy/conv/kernel"] = 32 * 16; n->expect["policy/conv/bias"] = 16;
+    n->expect["policy/fc/kernel"] = 16 * HW * HW; n->expect["policy/fc/bias"] = HW;
+    *out = n;
+    return AF_NET_OK;
+}
+
+void af_net_destroy(af_net* n) {
+    if (!n) return;
+    (void)hipSetDevice(n->device);
+    for (void* p : n->allocs) (void)hipFree(p);
+    delete n;
+}
+
+int af_net_set_variable(af_net* n, const char* name, const float* data, int64_t count) {
+    if (!n || !name || !data) return AF_NET_ERR_ARG;
+    auto it = n->expect.find(name);
+    if (it == n->expect.end() || (int64_t)it->second != count) return AF_NET_ERR_NAME;
+    n->vars[name].assign(data, data + count);
+    n->ready = false;
+    return AF_NET_OK;
+}
+
+int af_net_finalize(af_net* n) {
+    if (!n) return AF_NET_ERR_ARG;
+    for (auto& kv : n->expect) if (!n->vars.count(kv.first)) return AF_NET_ERR_STATE;
+    NET_HIP_OK(hipSetDevice(n->device));
+    for (void* p : n->allocs) (void)hipFree(p);
+    n->allocs.clear();
+    auto& V = n->vars;
+    int rc = AF_NET_OK;
+#define UP(dst, vec) if (!rc) rc = net_upload(n, &n->dst, (vec))
+    UP(stem_w, V["bone/conv1/kernel"]); UP(stem_b, V["bone/conv1/bias"]);
+    for (int i = 0; i < 5; ++i) {
+        const Block& b = kBlocks[i];
+        const std::string s = b.name;
+        UP(conv1_w[i], pack_conv(V[s + "_conv1/kernel"], 9, b.cin, b.cout));
+        UP(conv1_b[i], pad_bias(V[s + "_conv1/bias"], nullptr, b.cout));
+        UP(conv2_w[i], pack_conv(V[s + "_conv2/kernel"], 9, b.cout, b.cout));
+        UP(res_w[i], pack_conv(V[s + "_res/kernel"], 1, b.cin, b.cout));
+        UP(sum_b[i], pad_bias(V[s + "_conv2/bias"], &V[s + "_res/bias"], b.cout));
+    }
+    UP(vc_w, V["value/conv/kernel"]); UP(vc_b, V["value/conv/bias"]); UP(v1_w, V["value/fc1/kernel"]);
+    UP(v1_b, V["value/fc1/bias"]); UP(v2_w, V["value/fc2/kernel"]); UP(v2_b, V["value/fc2/bias"]);
+    UP(pc_w, V["policy/conv/kernel"]); UP(pc_b, V["policy/conv/bias"]); UP(pf_w, V["policy/fc/kernel"]);
+    UP(pf_b, V["policy/fc/bias"]);
+#undef UP
+    const size_t plane = (size_t)n->max_batch * n->PP;
+    if (!rc) rc = net_alloc(n, &n->f0, plane * 32, true);
+    for (int i = 0; i < 5 && !rc; ++i) {
+        rc = net_alloc(n, &n->g[i], plane * kBlocks[i].cout, true);
+        if (!rc) rc = net_alloc(n, &n->o[i], plane * kBlocks[i].cout, true);
+    }
+    if (rc) return rc;
+    n->ready = true;
+    return AF_NET_OK;
+}
+
+}  // extern "C"
+
+// tile-shape selection per cout width (tuning knob, see af_net_tune): index = cout_pad/32 - 1 (.. 3 for 128)
+static int g_shape[4] = {0, 0, 0, 0};
+
+template <int NT, int MT, int MINW>
+static void launch_shape(hipStream_t st, const ConvArgs& a) {
+    const int tiles = (a.rows + 31) / 32;
+    const int tasks = (tiles + MT - 1) / MT;
+    hipLaunchKernelGGL((af_conv_mfma<NT, MT, MINW>), dim3((tasks + 3) / 4), dim3(256), 0, st, a);
+}
+
+static void launch_conv(hipStream_t st, const ConvArgs& a) {
+    if (a.cout_pad == 128) {
+        switch (g_shape[3]) {
+            case 1: launch_shape<4, 1, 2>(st, a); break;
+            case 2: launch_shape<4, 1, 3>(st, a); break;
+            default: launch_shape<4, 2, 1>(st, a); break;
+        }
+    } else if (a.cout_pad == 64) {
+        switch (g_shape[1]) {
+            case 1: launch_shape<2, 2, 2>(st, a); break;
+            case 2: launch_shape<2, 2, 3>(st, a); break;
+            default: launch_shape<2, 4, 1>(st, a); break;
+        }
+    } else {
+        switch (g_shape[0]) {
+            case 1: launch_shape<1, 4, 2>(st, a); break;
+            case 2: launch_shape<1, 8, 1>(st, a); break;
+            case 3: launch_shape<1, 2, 4>(st, a); break;
+            default: launch_shape<1, 4, 1>(st, a); break;
+        }
+    }
+}
+
+extern "C" {
+
+int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, float* policy, float* value) {
+    if (!n || !planes || !policy || !value || batch < 1 || batch > n->max_batch) return AF_NET_ERR_ARG;
+    if (!n->ready) return AF_NET_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = n->S, HW = n->HW, WP = n->WP, PP = n->PP;
+    hipLaunchKernelGGL(af_stem_conv, dim3(batch), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, S, WP, PP);
+    const float* block_in[5] = {n->f0, n->o[0], n->o[1], n->o[1], n->o[3]};
+    for (int i = 0; i < 5; ++i) {
+        const Block& b = kBlocks[i];
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.rows = batch * HW; a.S = S; a.HW = HW; a.WP = WP; a.PP = PP; a.elu = 1;
+        a.cout = b.cout; a.cout_pad = pad32(b.cout);
+        // conv1 3x3 + ELU (network.py:54)
+        a.nseg = 1; a.seg[0] = ConvSeg{block_in[i], n->conv1_w[i], b.cin, 9};
+        a.bias = n->conv1_b[i]; a.out = n->g[i];
+        launch_conv(st, a);
+        // conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
+        a.nseg = 2; a.seg[0] = ConvSeg{n->g[i], n->conv2_w[i], b.cout, 9};
+        a.seg[1] = ConvSeg{block_in[i], n->res_w[i], b.cin, 1};
+        a.bias = n->sum_b[i]; a.out = n->o[i];
+        launch_conv(st, a);
+        if (i == 2)
+            hipLaunchKernelGGL(af_value_head, dim3(batch), dim3(256), 0, st, n->o[2], n->vc_w, n->vc_b, n->v1_w, n->v1_b,
+                               n->v2_w, n->v2_b, value, S, WP, PP);
+    }
+    if (HW <= 128) {
+        const size_t lds = ((size_t)16 * HW * 8 + 512 + 32) * 4;
+        hipLaunchKernelGGL((af_policy_head<8>), dim3((batch + 7) / 8), dim3(128), lds, st, n->o[4], n->pc_w, n->pc_b, n->pf_w,
+                           n->pf_b, policy, batch, S, WP, PP);
+    } else {
+        const size_t lds = ((size_t)16 * HW * 4 + 512 + 16) * 4;
+        hipLaunchKernelGGL((af_policy_head<4>), dim3((batch + 3) / 4), dim3(256), lds, st, n->o[4], n->pc_w, n->pc_b, n->pf_w,
+                           n->pf_b, policy, batch, S, WP, PP);
+    }
+    NET_HIP_OK(hipGetLastError());
+    return AF_NET_OK;
+}
+
+int af_net_tune(int32_t cout_pad, int32_t shape) {
+    if (cout_pad != 32 && cout_pad != 64 && cout_pad != 128) return AF_NET_ERR_ARG;
+    g_shape[cout_pad / 32 - 1] = shape;
+    return AF_NET_OK;
+}
+
+int64_t af_net_flops_per_position(const af_net* n) {
+    const int64_t HW = n->HW;
+    int64_t mac = 75 * 32 * HW;
+    for (const Block& b : kBlocks) mac += ((int64_t)9 * b.cin * b.cout + (int64_t)9 * b.cout * b.cout + (int64_t)b.cin * b.cout) * HW;
+    mac += 32 * 4 * HW + 4 * HW * 64 + 64 + 32 * 16 * HW + 16 * HW * HW;
+    return 2 * mac;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""ctypes binding of libaf_net.so (include/af_net.h): the hand-written fp32-MFMA forward pass.
+Used by ResNet.select_backend("hip"/"auto"); raises if the library is missing (no fallback here —
+the caller decides whether the torch-op path is acceptable)."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.environ.get("AF_NET_LIB") or os.path.join(_PKG, "_lib", "libaf_net.so")
+_lib = None
+
+
+class NetError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise ImportError(f"{_LIBPATH} not built (python -m alphafive_amd.build)")
+        L = C.CDLL(_LIBPATH)
+        vp = C.c_void_p
+        L.af_net_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.af_net_destroy.argtypes = [vp]
+        L.af_net_destroy.restype = None
+        L.af_net_set_variable.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
+        L.af_net_finalize.argtypes = [vp]
+        L.af_net_forward.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
+        L.af_net_flops_per_position.argtypes = [vp]
+        L.af_net_flops_per_position.restype = C.c_int64
+        L.af_net_strerror.argtypes = [C.c_int]
+        L.af_net_strerror.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise NetError(f"{what}: {lib().af_net_strerror(rc).decode()} (code {rc})")
+
+
+class HipNet(object):
+    """One af_net handle sized for `max_batch` positions on `device`."""
+
+    def __init__(self, variables, board_size, max_batch, device):
+        self.S, self.max_batch, self.device = board_size, max_batch, torch.device(device)
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _check(lib().af_net_create(board_size, max_batch, idx, C.byref(self._h)), "af_net_create")
+        for name, arr in variables.items():
+            a = np.ascontiguousarray(arr, np.float32)
+            _check(lib().af_net_set_variable(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size),
+                   f"af_net_set_variable({name})")
+        _check(lib().af_net_finalize(self._h), "af_net_finalize")
+        self.flops_per_position = int(lib().af_net_flops_per_position(self._h))
+        self.policy = torch.empty((max_batch, board_size * board_size), dtype=torch.float32, device=self.device)
+        self.value = torch.empty((max_batch,), dtype=torch.float32, device=self.device)
+
+    def __call__(self, planes):
+        B = planes.shape[0]
+        assert B <= self.max_batch and planes.is_contiguous() and planes.dtype == torch.float32
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().af_net_forward(self._h, stream, planes.data_ptr(), B, self.policy.data_ptr(), self.value.data_ptr()),
+               "af_net_forward")
+        return self.policy[:B], self.value[:B]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                lib().af_net_destroy(self._h)
+            except Exception:       # interpreter shutdown
+                pass
+            self._h = None
+
+    __del__ = close
+
+
+def make_eval(resnet):
+    """-> callable planes -> (prob, value) backed by the HIP kernels, or None when not applicable."""
+    if resnet.device.type != "cuda" or not (3 <= resnet.board_size <= 15):
+        return None
+    lib()
+    state = {"net": None}
+
+    def pv(planes):
+        B = planes.shape[0]
+        if state["net"] is None or state["net"].max_batch < B:
+            if state["net"] is not None:
+                state["net"].close()
+            state["net"] = HipNet(resnet.variables, resnet.board_size, B, resnet.device)
+        return state["net"](planes)
+
+    return pv
+
+
+def roofline_info():
+    return {"backend": "hip (af_net.hip: fp32 MFMA implicit-GEMM convs, fused bias/ELU/residual)",
+            "kernel": "af_net_forward = af_stem_conv + 10x af_conv_mfma<NT,MT> + af_value_head + af_policy_head "
+                      "(whole forward timed; af_conv_mfma carries 99 % of the FLOPs)"}
+
+
+def tune(cout_pad, shape):
+    """Benchmark knob: pick the MFMA tile shape for layers of width cout_pad (af_net_tune)."""
+    lib().af_net_tune.argtypes = [C.c_int32, C.c_int32]
+    _check(lib().af_net_tune(cout_pad, shape), "af_net_tune")

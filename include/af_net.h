@@ -1,0 +1,56 @@
+/*
+ * af_net.h — C ABI of the hand-written gfx950 forward pass of the reference's policy/value
+ * network (libaf_net.so).  Replaces, for the self-play path, what genData/network.py:90-97
+ * (ResNet.eval -> sess.run([prob, value])) executes: the graph of network.py:52-88,163-165
+ *   conv5x5(3->32)+ELU, residual(64), residual(128), value head (residual(32), 1x1->4, fc 64, fc 1,
+ *   tanh(x/2)), policy head (residual(64), residual(32), 1x1->16, fc S*S, softmax)
+ * in fp32 on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+ *
+ * Variables are handed over under their checkpoint names in TF layout (conv kernels HWIO
+ * [kh][kw][cin][cout], dense [in][out], flatten order NCHW), exactly as
+ * alphafive_amd.tensorbundle reads them from ckpt/alphaFive-*.  Plain pointers, int return
+ * codes (0 ok, <0 error), no exceptions; one handle per GPU; not thread-safe per handle.
+ */
+#ifndef AF_NET_H
+#define AF_NET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct af_net af_net;
+
+#define AF_NET_OK 0
+#define AF_NET_ERR_ARG   (-1)
+#define AF_NET_ERR_HIP   (-2)
+#define AF_NET_ERR_NAME  (-3)   /* unknown variable name or wrong element count */
+#define AF_NET_ERR_STATE (-4)   /* forward before finalize / missing variables */
+
+/* board_size S (3..16); max_batch = largest batch af_net_forward will be called with. */
+int af_net_create(int32_t board_size, int32_t max_batch, int32_t device, af_net** out);
+void af_net_destroy(af_net* n);
+
+/* Provide one variable (host pointer, fp32, TF layout) — e.g. "bone/block1_conv1/kernel". */
+int af_net_set_variable(af_net* n, const char* tf_name, const float* host_data, int64_t count);
+/* Repack (k-pair-major streams for the MFMA kernels) and upload; call after all 42 variables are set. */
+int af_net_finalize(af_net* n);
+
+/* planes_dev float32[batch][3][S][S] (utils.py:256 board_to_inputs layout) ->
+ * policy_dev float32[batch][S*S] (softmax probabilities), value_dev float32[batch].
+ * Asynchronous on `stream` (hipStream_t; NULL = default stream). */
+int af_net_forward(af_net* n, void* stream, const float* planes_dev, int32_t batch, float* policy_dev, float* value_dev);
+
+/* Tuning knob: choose the MFMA tile shape used for layers of width cout_pad (32/64/128);
+ * shape 0 = default.  Process-global; for benchmarking only. */
+int af_net_tune(int32_t cout_pad, int32_t shape);
+
+/* FLOPs (2*MAC) of one position's forward pass, as executed (direct convolution). */
+int64_t af_net_flops_per_position(const af_net* n);
+const char* af_net_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

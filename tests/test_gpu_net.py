@@ -1,0 +1,81 @@
+"""HIP forward pass (libaf_net.so through the C ABI) vs the fp64 restatement (1e-5, the tolerance
+BASELINE.json states for the value) and vs the plain PyTorch fp32 reference of the same graph."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import net_fp64
+
+pytestmark = pytest.mark.gpu
+W = os.path.join(GOLDEN, "alphaFive-6960.weights.npz")
+
+
+def _positions(S, B, seed=0):
+    rng = np.random.RandomState(seed)
+    x = np.zeros((B, 3, S, S), np.float32)
+    for b in range(B):
+        n = rng.randint(0, S * S - 1)
+        cells = rng.permutation(S * S)[:n + 1]
+        x[b, 0].reshape(-1)[cells[0:n:2]] = 1
+        x[b, 1].reshape(-1)[cells[1:n:2]] = 1
+        if b % 7:
+            x[b, 2].reshape(-1)[cells[n]] = 1
+    return x
+
+
+def test_hip_net_matches_fp64_restatement_and_torch_reference():
+    import torch
+    from alphafive_amd.network import ResNet
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    pv = net.select_backend("hip")
+    x = _positions(11, 512)
+    xt = torch.from_numpy(x).cuda()
+    p, v = pv(xt)
+    p, v = p.cpu().numpy().copy(), v.cpu().numpy().copy()
+    assert p.shape == (512, 121) and v.shape == (512,)
+    p64, v64 = net_fp64.forward(net.variables, x[:96])
+    assert np.abs(v[:96] - v64).max() < 1e-5          # BASELINE.json: value within 1e-5 (fp32)
+    assert np.abs(p[:96] - p64).max() < 1e-5
+    pt, vt = net.eval_device(xt)                       # plain PyTorch fp32 reference (MIOpen picks Winograd)
+    assert (torch.from_numpy(v).cuda() - vt).abs().max().item() < 5e-5
+    assert (torch.from_numpy(p).cuda() - pt).abs().max().item() < 5e-5
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+    # deterministic: same input, same bits
+    p2, v2 = pv(xt)
+    assert (p2.cpu().numpy() == p).all() and (v2.cpu().numpy() == v).all()
+    # SURVEY §8c sanity values of the shipped checkpoint
+    p0, v0 = pv(torch.zeros((1, 3, 11, 11), device="cuda"))
+    assert abs(float(v0[0]) - 0.10429) < 1e-5 and int(p0.argmax()) == 5 * 11 + 8
+
+
+@pytest.mark.parametrize("S,B", [(11, 1), (11, 7), (11, 33), (15, 40), (7, 100), (6, 65)])
+def test_hip_net_ragged_batches_and_board_sizes(S, B):
+    import torch
+    from alphafive_amd.network import ResNet
+    net = ResNet(S, device="cuda", seed=S)
+    if S == 11:
+        net.load_npz(W)
+    pv = net.select_backend("hip")
+    x = _positions(S, B, seed=B)
+    p, v = pv(torch.from_numpy(x).cuda())
+    p, v = p.cpu().numpy().copy(), v.cpu().numpy().copy()
+    p64, v64 = net_fp64.forward(net.variables, x[:24])
+    assert np.abs(v[:24] - v64).max() < 1e-5
+    assert np.abs(p[:24] - p64).max() < 1e-5
+    # batch independence: position b evaluated alone gives the same bits as inside the batch
+    p1, v1 = pv(torch.from_numpy(x[B - 1:B]).cuda())
+    p1, v1 = p1.clone(), v1.clone()                    # pv returns views of its output buffers
+    pb, vb = pv(torch.from_numpy(x).cuda())
+    assert (p1[0] == pb[B - 1]).all() and v1[0] == vb[B - 1]
+
+
+def test_flop_count_matches_survey():
+    from alphafive_amd import net_hip
+    from alphafive_amd.network import ResNet
+    net = ResNet(11, device="cuda")
+    h = net_hip.HipNet(net.variables, 11, 4, net.device)
+    assert h.flops_per_position == 118_727_264         # 59,363,632 MAC
+    h.close()

@@ -1,0 +1,16 @@
+#!/usr/bin/env python
+"""Per-kernel mean of rocprofv3 --pmc counters from a rocpd SQLite db. usage: pmc_summary.py x.db [name-filter]"""
+import sqlite3, sys, collections
+db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
+flt = sys.argv[2] if len(sys.argv) > 2 else ""
+cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+print("# columns:", cols, file=sys.stderr)
+name_col = "kernel_name" if "kernel_name" in cols else "name"
+rows = cur.execute(f"select {name_col}, counter_name, value, dispatch_id from counters_collection").fetchall()
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for k, c, v, d in rows:
+    if flt in k: acc[k][c].append(v)
+for k in acc:
+    print(k[:90])
+    for c, vs in sorted(acc[k].items()):
+        print(f"   {c:<34} n={len(vs):<5} mean={sum(vs)/len(vs):.4g}")

@@ -1,0 +1,13 @@
+"""Lean probe for counter collection: only the HIP net, a handful of forwards."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from alphafive_amd.network import ResNet
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B = int(os.environ.get("B", 4096)); N = int(os.environ.get("N", 3))
+net = ResNet(11, device="cuda", seed=1); net.load_npz(os.path.join(R, "tests/golden/alphaFive-6960.weights.npz"))
+x = (torch.rand((B, 3, 11, 11), device="cuda") < 0.2).float()
+pv = net.select_backend("hip")
+for _ in range(N): pv(x)
+torch.cuda.synchronize()
+print("done")
