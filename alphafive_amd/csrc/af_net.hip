@@ -31,6 +31,8 @@
 #include "af_net.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4 floats, only 4-byte aligned
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 struct ConvSeg {
     const float* in;   // [batch][cin][PP]
@@ -180,6 +182,203 @@ __global__ __launch_bounds__(256, MINW) void af_conv_mfma(ConvArgs A) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) on the matrix cores: Y = A^T [ (G g G^T) (.) (B^T d B) ] A per 2x2 output
+// tile, the 16 element-wise products becoming 16 independent [cout x cin] x [cin x tile] GEMMs:
+// 16 MFMA k-steps per cin pair cover 32 tiles = 128 output pixels (direct: 9 k-steps cover 32
+// pixels) => 2.25x fewer MFMA instructions for the layers that hold 97 % of the FLOPs.
+//   * one wave = 32 tiles x 32 couts; all 16 Winograd-domain accumulators M[xi][nu] stay in
+//     registers (256 AGPRs), so nothing is staged through memory: the input transform B^T d B
+//     (32 adds on the lane's own 4x4 patch, loaded as 16 dwords) happens between the loads and the
+//     MFMAs, the output transform A^T M A (24 adds per cout row) in the epilogue, fused with bias,
+//     the residual projection, ELU and the store into the next layer's padded layout.
+//   * the block's 1x1 projection is a 3x3 kernel with only the centre tap set; in the Winograd
+//     domain only (xi,nu) in {1,2}^2 are non-zero, so it is 4 extra k-steps per cin pair into
+//     M[1][1], M[1][2], M[2][1], M[2][2] and needs only the 2x2 centre of the patch.
+//   * U = G g G^T is computed once on the host (fp64, rounded to fp32) and packed k-pair-major
+//     [cin/2][2][cout][16] (a lane's 16 values = 4 dwordx4 loads); the 4 waves of a workgroup take 4 tile blocks of the SAME cout tile so
+//     the weight stream is shared in L1.
+// Plane layout: tiles need rows/cols 2t-1 .. 2t+2, so planes are padded to (2*ceil(S/2)+2)^2.
+struct WinoArgs {
+    const float* in;     // [batch][cin][PP]   input of the 3x3 convolution
+    const float* u;      // [cin/2][2][cout][16]
+    const float* in2;    // [batch][cin2][PP]  input of the 1x1 projection (or nullptr)
+    const float* u2;     // [cin2/2][2][cout][4]
+    const float* bias;   // [cout]
+    float* out;          // [batch][cout][PP]
+    int cin, cin2, cout, ntiles, T, S, WP, PP;
+};
+
+__global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int nct = A.cout >> 5;
+    const int ct = blockIdx.x % nct;
+    const int tb = (blockIdx.x / nct) * 4 + wave;
+    if (tb * 32 >= A.ntiles) return;
+    const int q = tb * 32 + col;
+    const bool valid = q < A.ntiles;
+    const int qq = valid ? q : 0;
+    const int TT = A.T * A.T;
+    const int pos = qq / TT;
+    const int t_ = qq - pos * TT;
+    const int ty = t_ / A.T, tx = t_ - ty * A.T;
+    const int WP = A.WP, PP = A.PP, cout = A.cout;
+    const int poff0 = 2 * ty * WP + 2 * tx;
+
+    f32x16 M[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) M[x][r] = 0.0f;
+
+    const uint32_t wlane = (uint32_t)(kh * cout + ct * 32 + col);
+    // Both k loops run a 4-deep register ring: the operands of phase p+3 are requested while phase p
+    // computes (16 MFMAs = 1024 cycles per phase => >= 3072 cycles for a load to land), and the 8-12
+    // wide loads + the transform adds of a phase are spread between its MFMAs by sched_group_barrier.
+    {   // ---- 3x3 segment: phase = one cin pair (16 MFMAs) ----
+        const char* __restrict__ inb = reinterpret_cast<const char*>(A.in);
+        const char* __restrict__ ub = reinterpret_cast<const char*>(A.u);
+        const uint32_t boff = (uint32_t)(pos * A.cin * PP + poff0 + kh * PP) * 4u;
+        const uint32_t woff = wlane * 64u;               // 16 floats per (kh, cout)
+        const int npairs = A.cin / 2;                    // multiple of 4
+        f4u d0[4], d1[4], d2[4], d3[4];
+        float4 u0[4], u1[4], u2[4], u3[4];
+        auto load_pair = [&](int c, f4u (&d)[4], float4 (&u)[4]) {
+            c = c < npairs ? c : npairs - 1;             // tail: harmless re-load instead of a branch
+            const char* ip = inb + (ptrdiff_t)(2 * c) * PP * 4;
+            const char* up = ub + (size_t)c * 2 * cout * 64;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                // one patch row = 4 consecutive floats (4-byte aligned)
+                d[r] = *reinterpret_cast<const f4u*>(ip + (ptrdiff_t)(r * WP) * 4 + (size_t)boff);
+                u[r] = *reinterpret_cast<const float4*>(up + (size_t)r * 16 + (size_t)woff);
+            }
+        };
+        auto compute_pair = [&](f4u (&d)[4], float4 (&u)[4]) {
+            float t[16], v[16];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                // t = B^T d
+                t[0 + s] = d[0][s] - d[2][s];
+                t[4 + s] = d[1][s] + d[2][s];
+                t[8 + s] = d[2][s] - d[1][s];
+                t[12 + s] = d[1][s] - d[3][s];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                // v = t B
+                v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
+                v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+                v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+                v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                M[4 * x + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].x, v[4 * x + 0], M[4 * x + 0], 0, 0, 0);
+                M[4 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].y, v[4 * x + 1], M[4 * x + 1], 0, 0, 0);
+                M[4 * x + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].z, v[4 * x + 2], M[4 * x + 2], 0, 0, 0);
+                M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, v[4 * x + 3], M[4 * x + 3], 0, 0, 0);
+            }
+        };
+        auto phase = [&](int c_load, f4u (&dl)[4], float4 (&ul)[4], f4u (&dc)[4], float4 (&uc)[4]) {
+            load_pair(c_load, dl, ul);
+            compute_pair(dc, uc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_pair(0, d0, u0);
+        load_pair(1, d1, u1);
+        load_pair(2, d2, u2);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < npairs; c += 4) {
+            phase(c + 3, d3, u3, d0, u0);
+            phase(c + 4, d0, u0, d1, u1);
+            phase(c + 5, d1, u1, d2, u2);
+            phase(c + 6, d2, u2, d3, u3);
+        }
+    }
+    if (A.in2) {   // ---- 1x1 projection segment: phase = 4 cin pairs (16 MFMAs) ----
+        const char* __restrict__ inb = reinterpret_cast<const char*>(A.in2);
+        const char* __restrict__ ub = reinterpret_cast<const char*>(A.u2);
+        const uint32_t boff = (uint32_t)(pos * A.cin2 * PP + poff0 + kh * PP + WP + 1) * 4u;   // patch centre (1,1)
+        const uint32_t woff = wlane * 16u;               // 4 floats per (kh, cout)
+        const int nph = A.cin2 / 8;                      // multiple of 4
+        f2u d0[4][2], d1[4][2], d2[4][2], d3[4][2];
+        float4 u0[4], u1[4], u2[4], u3[4];
+        auto load_ph = [&](int q, f2u (&d)[4][2], float4 (&u)[4]) {
+            q = q < nph ? q : nph - 1;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const char* ip = inb + (ptrdiff_t)(2 * (4 * q + h)) * PP * 4;
+                const char* up = ub + (size_t)(4 * q + h) * 2 * cout * 16;
+                d[h][0] = *reinterpret_cast<const f2u*>(ip + (size_t)boff);
+                d[h][1] = *reinterpret_cast<const f2u*>(ip + (ptrdiff_t)WP * 4 + (size_t)boff);
+                u[h] = *reinterpret_cast<const float4*>(up + (size_t)woff);
+            }
+        };
+        auto compute_ph = [&](f2u (&d)[4][2], float4 (&u)[4]) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float t11 = d[h][0][0] + d[h][1][0], t12 = d[h][0][1] + d[h][1][1];   // (B^T d) rows 1,2, cols 1,2
+                const float t21 = d[h][1][0] - d[h][0][0], t22 = d[h][1][1] - d[h][0][1];
+                M[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[h].x, t11 + t12, M[5], 0, 0, 0);
+                M[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[h].y, t12 - t11, M[6], 0, 0, 0);
+                M[9] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[h].z, t21 + t22, M[9], 0, 0, 0);
+                M[10] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[h].w, t22 - t21, M[10], 0, 0, 0);
+            }
+        };
+        auto phase = [&](int q_load, f2u (&dl)[4][2], float4 (&ul)[4], f2u (&dc)[4][2], float4 (&uc)[4]) {
+            load_ph(q_load, dl, ul);
+            compute_ph(dc, uc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_ph(0, d0, u0);
+        load_ph(1, d1, u1);
+        load_ph(2, d2, u2);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < nph; q += 4) {
+            phase(q + 3, d3, u3, d0, u0);
+            phase(q + 4, d0, u0, d1, u1);
+            phase(q + 5, d1, u1, d2, u2);
+            phase(q + 6, d2, u2, d3, u3);
+        }
+    }
+    // ---- output transform Y = A^T M A, bias, ELU, store the 2x2 tile ----
+    const bool ok0y = 2 * ty < A.S, ok1y = 2 * ty + 1 < A.S, ok0x = 2 * tx < A.S, ok1x = 2 * tx + 1 < A.S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float bv = A.bias[co];
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = M[0 + j][r] + M[4 + j][r] + M[8 + j][r];
+            s1[j] = M[4 + j][r] - M[8 + j][r] - M[12 + j][r];
+        }
+        const float y00 = elu1(s0[0] + s0[1] + s0[2] + bv), y01 = elu1(s0[1] - s0[2] - s0[3] + bv);
+        const float y10 = elu1(s1[0] + s1[1] + s1[2] + bv), y11 = elu1(s1[1] - s1[2] - s1[3] + bv);
+        float* o = A.out + (size_t)(pos * cout + co) * PP + poff0 + WP + 1;     // output pixel (2ty, 2tx)
+        if (valid) {
+            if (ok0y && ok0x) o[0] = y00;
+            if (ok0y && ok1x) o[1] = y01;
+            if (ok1y && ok0x) o[WP] = y10;
+            if (ok1y && ok1x) o[WP + 1] = y11;
+        }
+    }
+}
+
 // stem: conv 5x5 SAME 3->32 + ELU (network.py:63), one block per position, one thread per pixel
 __global__ __launch_bounds__(256) void af_stem_conv(const float* __restrict__ planes, const float* __restrict__ w /*[75][32]*/,
                                                     const float* __restrict__ bias, float* __restrict__ out, int S, int WP, int PP) {
@@ -286,6 +485,7 @@ __global__ __launch_bounds__(256) void af_policy_head(const float* __restrict__ 
     const int j = t < HW ? t : HW - 1;
 #pragma unroll
     for (int p = 0; p < PPB; ++p) acc[p] = bf[j];
+#pragma unroll 8
     for (int k = 0; k < 16 * HW; ++k) {
         const float wv = wf[(size_t)k * HW + j];
         const float4* xr = reinterpret_cast<const float4*>(sh + (size_t)k * PPB);
@@ -352,6 +552,11 @@ struct af_net {
     // device weights
     float *stem_w, *stem_b;
     float *conv1_w[5], *conv1_b[5], *conv2_w[5], *res_w[5], *sum_b[5];
+    float *wino1_u[5], *wino2_u[5], *winor_u[5];
+    int T;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events;
+    hipEvent_t ev_start = nullptr;
     float *vc_w, *vc_b, *v1_w, *v1_b, *v2_w, *v2_b, *pc_w, *pc_b, *pf_w, *pf_b;
     // activations [max_batch][C][PP]
     float *f0, *g[5], *o[5];
@@ -385,6 +590,33 @@ static std::vector<float> pack_conv(const std::vector<float>& w, int taps, int c
                 out[((((size_t)(c / 2) * taps + t) * 2) + (c & 1)) * cp + co] = w[((size_t)t * cin + c) * cout + co];
     return out;
 }
+// Winograd weights U = G g G^T per (cin, cout), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], packed
+// [cin/2][2][cout][npos] (one lane's npos values contiguous).  taps == 9: all 16 (xi,nu); taps == 1: the centre-tap kernel of a 1x1
+// projection, whose only non-zero positions are (1,1),(1,2),(2,1),(2,2).
+static std::vector<float> pack_wino(const std::vector<float>& w, int taps, int cin, int cout) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    static const int kCentre[4] = {5, 6, 9, 10};
+    const int npos = taps == 9 ? 16 : 4;
+    std::vector<float> out((size_t)cin * npos * cout, 0.0f);
+    for (int c = 0; c < cin; ++c)
+        for (int co = 0; co < cout; ++co) {
+            double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            if (taps == 9) {
+                for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = w[((size_t)t * cin + c) * cout + co];
+            } else {
+                g[1][1] = w[(size_t)c * cout + co];
+            }
+            for (int p = 0; p < npos; ++p) {
+                const int x = taps == 9 ? p : kCentre[p];
+                const int xi = x / 4, nu = x % 4;
+                double u = 0.0;
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) u += G[xi][i] * g[i][j] * G[nu][j];
+                out[((((size_t)(c / 2) * 2) + (c & 1)) * cout + co) * npos + p] = (float)u;
+            }
+        }
+    return out;
+}
 static std::vector<float> pad_bias(const std::vector<float>& a, const std::vector<float>* b, int cout) {
     std::vector<float> out(pad32(cout), 0.0f);
     for (int i = 0; i < cout; ++i) out[i] = a[i] + (b ? (*b)[i] : 0.0f);
@@ -408,7 +640,10 @@ int af_net_create(int32_t S, int32_t max_batch, int32_t device, af_net** out) {
     if (!out || S < 3 || S > 16 || max_batch < 1) return AF_NET_ERR_ARG;
     NET_HIP_OK(hipSetDevice(device));
     af_net* n = new af_net();
-    n->S = S; n->HW = S * S; n->WP = S + 2; n->PP = ((S + 2) * (S + 2) + 15) / 16 * 16;
+    n->S = S; n->HW = S * S;
+    n->T = (S + 1) / 2;                      // 2x2 output tiles per board side (Winograd)
+    n->WP = 2 * n->T + 2;                    // plane padded so every tile's 4x4 patch is in bounds
+    n->PP = (n->WP * n->WP + 15) / 16 * 16;
     n->max_batch = max_batch; n->device = device;
     const size_t HW = n->HW;
     n->expect["bone/conv1/kernel"] = 75 * 32; n->expect["bone/conv1/bias"] = 32;
@@ -461,6 +696,9 @@ int af_net_finalize(af_net* n) {
         UP(conv2_w[i], pack_conv(V[s + "_conv2/kernel"], 9, b.cout, b.cout));
         UP(res_w[i], pack_conv(V[s + "_res/kernel"], 1, b.cin, b.cout));
         UP(sum_b[i], pad_bias(V[s + "_conv2/bias"], &V[s + "_res/bias"], b.cout));
+        UP(wino1_u[i], pack_wino(V[s + "_conv1/kernel"], 9, b.cin, b.cout));
+        UP(wino2_u[i], pack_wino(V[s + "_conv2/kernel"], 9, b.cout, b.cout));
+        UP(winor_u[i], pack_wino(V[s + "_res/kernel"], 1, b.cin, b.cout));
     }
     UP(vc_w, V["value/conv/kernel"]); UP(vc_b, V["value/conv/bias"]); UP(v1_w, V["value/fc1/kernel"]);
     UP(v1_b, V["value/fc1/bias"]); UP(v2_w, V["value/fc2/kernel"]); UP(v2_b, V["value/fc2/bias"]);
@@ -482,6 +720,17 @@ int af_net_finalize(af_net* n) {
 
 // tile-shape selection per cout width (tuning knob, see af_net_tune): index = cout_pad/32 - 1 (.. 3 for 128)
 static int g_shape[4] = {0, 0, 0, 0};
+static int g_wino = 1;   // 1: 3x3 layers through af_conv_wino (default); 0: direct af_conv_mfma
+
+static void launch_wino(hipStream_t st, const af_net* n, int batch, const float* in, const float* u, int cin,
+                        const float* in2, const float* u2, int cin2, const float* bias, float* out, int cout) {
+    WinoArgs a;
+    a.in = in; a.u = u; a.in2 = in2; a.u2 = u2; a.bias = bias; a.out = out;
+    a.cin = cin; a.cin2 = cin2; a.cout = cout; a.T = n->T; a.S = n->S; a.WP = n->WP; a.PP = n->PP;
+    a.ntiles = batch * n->T * n->T;
+    const int ntb = (a.ntiles + 31) / 32;
+    hipLaunchKernelGGL(af_conv_wino, dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
+}
 
 template <int NT, int MT, int MINW>
 static void launch_shape(hipStream_t st, const ConvArgs& a) {
@@ -515,46 +764,101 @@ static void launch_conv(hipStream_t st, const ConvArgs& a) {
 
 extern "C" {
 
-int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, float* policy, float* value) {
-    if (!n || !planes || !policy || !value || batch < 1 || batch > n->max_batch) return AF_NET_ERR_ARG;
-    if (!n->ready) return AF_NET_ERR_STATE;
-    hipStream_t st = (hipStream_t)stream;
+}  // extern "C"
+
+static int g_substreams = 1;     // >1: split the batch into that many sub-batches, one HIP stream each
+static int g_subbatch = 0;       // 0: batch / g_substreams
+
+// forward pass of positions [b0, b0+batch) on stream st
+static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int b0, int batch, float* policy_all, float* value_all) {
     const int S = n->S, HW = n->HW, WP = n->WP, PP = n->PP;
-    hipLaunchKernelGGL(af_stem_conv, dim3(batch), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, S, WP, PP);
-    const float* block_in[5] = {n->f0, n->o[0], n->o[1], n->o[1], n->o[3]};
+    const float* planes = planes_all + (size_t)b0 * 3 * HW;
+    float* policy = policy_all + (size_t)b0 * HW;
+    float* value = value_all + b0;
+    const size_t po = (size_t)b0 * PP;
+    float* f0 = n->f0 + po * 32;
+    float* g[5];
+    float* o[5];
+    for (int i = 0; i < 5; ++i) { g[i] = n->g[i] + po * kBlocks[i].cout; o[i] = n->o[i] + po * kBlocks[i].cout; }
+    hipLaunchKernelGGL(af_stem_conv, dim3(batch), dim3(256), 0, st, planes, n->stem_w, n->stem_b, f0, S, WP, PP);
+    const float* block_in[5] = {f0, o[0], o[1], o[1], o[3]};
     for (int i = 0; i < 5; ++i) {
         const Block& b = kBlocks[i];
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        a.rows = batch * HW; a.S = S; a.HW = HW; a.WP = WP; a.PP = PP; a.elu = 1;
-        a.cout = b.cout; a.cout_pad = pad32(b.cout);
-        // conv1 3x3 + ELU (network.py:54)
-        a.nseg = 1; a.seg[0] = ConvSeg{block_in[i], n->conv1_w[i], b.cin, 9};
-        a.bias = n->conv1_b[i]; a.out = n->g[i];
-        launch_conv(st, a);
-        // conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
-        a.nseg = 2; a.seg[0] = ConvSeg{n->g[i], n->conv2_w[i], b.cout, 9};
-        a.seg[1] = ConvSeg{block_in[i], n->res_w[i], b.cin, 1};
-        a.bias = n->sum_b[i]; a.out = n->o[i];
-        launch_conv(st, a);
+        if (g_wino) {
+            // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
+            launch_wino(st, n, batch, block_in[i], n->wino1_u[i], b.cin, nullptr, nullptr, 0, n->conv1_b[i], g[i], b.cout);
+            launch_wino(st, n, batch, g[i], n->wino2_u[i], b.cout, block_in[i], n->winor_u[i], b.cin, n->sum_b[i], o[i], b.cout);
+        } else {
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rows = batch * HW; a.S = S; a.HW = HW; a.WP = WP; a.PP = PP; a.elu = 1;
+            a.cout = b.cout; a.cout_pad = pad32(b.cout);
+            a.nseg = 1; a.seg[0] = ConvSeg{block_in[i], n->conv1_w[i], b.cin, 9};
+            a.bias = n->conv1_b[i]; a.out = g[i];
+            launch_conv(st, a);
+            a.nseg = 2; a.seg[0] = ConvSeg{g[i], n->conv2_w[i], b.cout, 9};
+            a.seg[1] = ConvSeg{block_in[i], n->res_w[i], b.cin, 1};
+            a.bias = n->sum_b[i]; a.out = o[i];
+            launch_conv(st, a);
+        }
         if (i == 2)
-            hipLaunchKernelGGL(af_value_head, dim3(batch), dim3(256), 0, st, n->o[2], n->vc_w, n->vc_b, n->v1_w, n->v1_b,
+            hipLaunchKernelGGL(af_value_head, dim3(batch), dim3(256), 0, st, o[2], n->vc_w, n->vc_b, n->v1_w, n->v1_b,
                                n->v2_w, n->v2_b, value, S, WP, PP);
     }
     if (HW <= 128) {
         const size_t lds = ((size_t)16 * HW * 8 + 512 + 32) * 4;
-        hipLaunchKernelGGL((af_policy_head<8>), dim3((batch + 7) / 8), dim3(128), lds, st, n->o[4], n->pc_w, n->pc_b, n->pf_w,
+        hipLaunchKernelGGL((af_policy_head<8>), dim3((batch + 7) / 8), dim3(128), lds, st, o[4], n->pc_w, n->pc_b, n->pf_w,
                            n->pf_b, policy, batch, S, WP, PP);
     } else {
         const size_t lds = ((size_t)16 * HW * 4 + 512 + 16) * 4;
-        hipLaunchKernelGGL((af_policy_head<4>), dim3((batch + 3) / 4), dim3(256), lds, st, n->o[4], n->pc_w, n->pc_b, n->pf_w,
+        hipLaunchKernelGGL((af_policy_head<4>), dim3((batch + 3) / 4), dim3(256), lds, st, o[4], n->pc_w, n->pc_b, n->pf_w,
                            n->pf_b, policy, batch, S, WP, PP);
     }
     NET_HIP_OK(hipGetLastError());
     return AF_NET_OK;
 }
 
+extern "C" {
+
+int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, float* policy, float* value) {
+    if (!n || !planes || !policy || !value || batch < 1 || batch > n->max_batch) return AF_NET_ERR_ARG;
+    if (!n->ready) return AF_NET_ERR_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = g_substreams;
+    if (ns <= 1 || batch < 64 * ns) return forward_range(n, st, planes, 0, batch, policy, value);
+    // sub-batches in flight on side streams: each chain's activations (<= 266 KB/position between two
+    // layers) stay inside the 256 MB Infinity Cache, and one chain's kernel tails overlap another's bodies
+    if ((int)n->streams.size() < ns) {
+        while ((int)n->streams.size() < ns) {
+            hipStream_t side_stream;
+            hipEvent_t side_event;
+            NET_HIP_OK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            NET_HIP_OK(hipEventCreateWithFlags(&side_event, hipEventDisableTiming));
+            n->streams.push_back(side_stream);
+            n->events.push_back(side_event);
+        }
+        NET_HIP_OK(hipEventCreateWithFlags(&n->ev_start, hipEventDisableTiming));
+    }
+    NET_HIP_OK(hipEventRecord(n->ev_start, st));
+    const int sub = g_subbatch > 0 ? g_subbatch : ((batch + ns - 1) / ns + 31) / 32 * 32;
+    for (int i = 0; i < ns; ++i) NET_HIP_OK(hipStreamWaitEvent(n->streams[i], n->ev_start, 0));
+    int k = 0;
+    for (int b0 = 0; b0 < batch; b0 += sub, ++k) {
+        const int nb = batch - b0 < sub ? batch - b0 : sub;
+        const int rc = forward_range(n, n->streams[k % ns], planes, b0, nb, policy, value);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < ns; ++i) {
+        NET_HIP_OK(hipEventRecord(n->events[i], n->streams[i]));
+        NET_HIP_OK(hipStreamWaitEvent(st, n->events[i], 0));
+    }
+    return AF_NET_OK;
+}
+
 int af_net_tune(int32_t cout_pad, int32_t shape) {
+    if (cout_pad == 0) { g_wino = shape ? 1 : 0; return AF_NET_OK; }     // 0: select Winograd (1) / direct (0)
+    if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
+    if (cout_pad == 2) { g_subbatch = shape; return AF_NET_OK; }                     // 2: sub-batch size (0 = batch/streams)
     if (cout_pad != 32 && cout_pad != 64 && cout_pad != 128) return AF_NET_ERR_ARG;
     g_shape[cout_pad / 32 - 1] = shape;
     return AF_NET_OK;
