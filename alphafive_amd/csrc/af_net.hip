@@ -241,18 +241,22 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
         const char* __restrict__ ub = reinterpret_cast<const char*>(A.u);
         const uint32_t boff = (uint32_t)(pos * A.cin * PP + poff0 + kh * PP) * 4u;
         const uint32_t woff = wlane * 64u;               // 16 floats per (kh, cout)
-        const int npairs = A.cin / 2;                    // multiple of 4
-        f4u d0[4], d1[4], d2[4], d3[4];
+        const int npairs = A.cin / 2;                    // multiple of 8
+        // activations (first touch comes from HBM / Infinity Cache) ride an 8-deep ring, weights (L2) a 4-deep one
+        f4u d0[4], d1[4], d2[4], d3[4], d4[4], d5[4], d6[4], d7[4];
         float4 u0[4], u1[4], u2[4], u3[4];
-        auto load_pair = [&](int c, f4u (&d)[4], float4 (&u)[4]) {
+        auto load_d = [&](int c, f4u (&d)[4]) {
             c = c < npairs ? c : npairs - 1;             // tail: harmless re-load instead of a branch
             const char* ip = inb + (ptrdiff_t)(2 * c) * PP * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                  // one patch row = 4 consecutive floats (4-byte aligned)
+                d[r] = *reinterpret_cast<const f4u*>(ip + (ptrdiff_t)(r * WP) * 4 + (size_t)boff);
+        };
+        auto load_u = [&](int c, float4 (&u)[4]) {
+            c = c < npairs ? c : npairs - 1;
             const char* up = ub + (size_t)c * 2 * cout * 64;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                // one patch row = 4 consecutive floats (4-byte aligned)
-                d[r] = *reinterpret_cast<const f4u*>(ip + (ptrdiff_t)(r * WP) * 4 + (size_t)boff);
-                u[r] = *reinterpret_cast<const float4*>(up + (size_t)r * 16 + (size_t)woff);
-            }
+            for (int r = 0; r < 4; ++r) u[r] = *reinterpret_cast<const float4*>(up + (size_t)r * 16 + (size_t)woff);
         };
         auto compute_pair = [&](f4u (&d)[4], float4 (&u)[4]) {
             float t[16], v[16];
@@ -278,8 +282,9 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
                 M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, v[4 * x + 3], M[4 * x + 3], 0, 0, 0);
             }
         };
-        auto phase = [&](int c_load, f4u (&dl)[4], float4 (&ul)[4], f4u (&dc)[4], float4 (&uc)[4]) {
-            load_pair(c_load, dl, ul);
+        auto phase = [&](int c, f4u (&dl)[4], float4 (&ul)[4], f4u (&dc)[4], float4 (&uc)[4]) {
+            load_d(c + 7, dl);
+            load_u(c + 3, ul);
             compute_pair(dc, uc);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -291,15 +296,18 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        load_pair(0, d0, u0);
-        load_pair(1, d1, u1);
-        load_pair(2, d2, u2);
+        load_d(0, d0); load_d(1, d1); load_d(2, d2); load_d(3, d3); load_d(4, d4); load_d(5, d5); load_d(6, d6);
+        load_u(0, u0); load_u(1, u1); load_u(2, u2);
         __builtin_amdgcn_sched_barrier(0);
-        for (int c = 0; c < npairs; c += 4) {
-            phase(c + 3, d3, u3, d0, u0);
-            phase(c + 4, d0, u0, d1, u1);
-            phase(c + 5, d1, u1, d2, u2);
-            phase(c + 6, d2, u2, d3, u3);
+        for (int c = 0; c < npairs; c += 8) {
+            phase(c + 0, d7, u3, d0, u0);
+            phase(c + 1, d0, u0, d1, u1);
+            phase(c + 2, d1, u1, d2, u2);
+            phase(c + 3, d2, u2, d3, u3);
+            phase(c + 4, d3, u3, d4, u0);
+            phase(c + 5, d4, u0, d5, u1);
+            phase(c + 6, d5, u1, d6, u2);
+            phase(c + 7, d6, u2, d7, u3);
         }
     }
     if (A.in2) {   // ---- 1x1 projection segment: phase = 4 cin pairs (16 MFMAs) ----

@@ -165,6 +165,14 @@ class ResNet(object):
         self._backend = "torch"
         return self.eval_device
 
+    def flops_per_position(self):
+        """2*MAC of one forward pass (direct convolution), any board size."""
+        HW = self.board_size ** 2
+        mac = 75 * 32 * HW + 32 * 4 * HW + 4 * HW * 64 + 64 + 32 * 16 * HW + 16 * HW * HW
+        for _, cin, cout in _BLOCKS:
+            mac += (9 * cin * cout + 9 * cout * cout + cin * cout) * HW
+        return 2 * mac
+
     def roofline_info(self, pv=None):
         if getattr(self, "_backend", "torch") == "hip":
             from . import net_hip

@@ -54,8 +54,9 @@ def cpu_baseline(cfg, weights, budget_s=20.0):
     import oracle
     from alphafive_amd.network import ResNet
     torch.set_num_threads(1)
-    net = ResNet(cfg.board_size, device="cpu")
-    net.load_npz(weights)
+    net = ResNet(cfg.board_size, device="cpu", seed=0)
+    if weights:
+        net.load_npz(weights)
     pl = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=0, game_id=0, pv_fn=net.eval)
     board = np.zeros((cfg.board_size, cfg.board_size), np.int8)
     state, last, plies = oracle.board_to_state(board), None, 0
@@ -83,6 +84,7 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=500)
     ap.add_argument("--upper", type=int, default=642)
+    ap.add_argument("--board", type=int, default=11, help="board size (15 with --sims 800 --upper 942 = BASELINE configs[3])")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,11 +111,12 @@ def main():
     from alphafive_amd.network import ResNet
     from alphafive_amd import dist as afdist
 
-    cfg = make_cfg(args.sims, args.upper)
+    cfg = make_cfg(args.sims, args.upper, args.board)
     G, C = args.games, cfg.board_size ** 2
     weights = os.path.join(REPO, "tests", "golden", "alphaFive-6960.weights.npz")
-    net = ResNet(cfg.board_size, device=dev)
-    net.load_npz(weights)
+    net = ResNet(cfg.board_size, device=dev, seed=0)
+    if cfg.board_size == 11:
+        net.load_npz(weights)                     # other sizes: random init of the same architecture (no checkpoint exists)
     if world > 1:
         afdist.broadcast_weights(net, src=0)      # one 3 MB broadcast, as a weight update would do
     pv = net.select_backend(args.net)
@@ -190,15 +193,19 @@ def main():
         n_ticks = len(ev_tick)
         tick_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_tick]))
         net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net]))
-        net_tflops = G * FLOP_PER_POSITION / (net_ms * 1e-3) / 1e12
+        flop_pos = FLOP_PER_POSITION if cfg.board_size == 11 else net.flops_per_position()
+        net_tflops = G * flop_pos / (net_ms * 1e-3) / 1e12
         tree_gbs = tree_bytes(d, C) / n_ticks / (tick_ms * 1e-3) / 1e9
         roof = net.roofline_info(pv)
         out = {
-            "metric": "self-play moves/sec (11x11, 500 sims/move)", "value": total_plies / t, "unit": "moves/s",
+            "metric": "self-play moves/sec (%dx%d, %d sims/move)" % (cfg.board_size, cfg.board_size, args.sims), "value": total_plies / t, "unit": "moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {G} concurrent 11x11 games per GPU, {args.sims} sims/move "
-                                   f"(cap {args.upper}), training-mode MCTS, alphaFive-6960 net fp32, batched leaf eval",
+            "config": {"workload": (f"BASELINE configs[1]: {G} concurrent 11x11 games per GPU, {args.sims} sims/move "
+                                    f"(cap {args.upper}), training-mode MCTS, alphaFive-6960 net fp32, batched leaf eval")
+                       if cfg.board_size == 11 else
+                       (f"BASELINE configs[3]-style: {G} concurrent {cfg.board_size}x{cfg.board_size} games per GPU, "
+                        f"{args.sims} sims/move (cap {args.upper}), random-init net of the same architecture, fp32"),
                        "games_per_gpu": G, "sims_per_move": args.sims, "net_backend": roof["backend"],
                        "step": "ticks until the batch commits G more plies", "ticks_timed_rank0": n_ticks,
                        "sims_per_ply_rank0": d["sims"] / max(1, d["plies"]),
@@ -208,14 +215,14 @@ def main():
             "roofline": {"kernel": roof["kernel"], "bound": "mfma", "achieved": net_tflops,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": net_tflops / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": None, "ms_per_launch": net_ms,
-                         "flop_per_launch": G * FLOP_PER_POSITION},
-            "tree_roofline": {"kernel": "af_tick_kernel<2>", "bound": "hbm", "achieved": tree_gbs,
+                         "flop_per_launch": G * flop_pos},
+            "tree_roofline": {"kernel": "af_tick_kernel<%d>" % (2 if C <= 128 else 4), "bound": "hbm", "achieved": tree_gbs,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": None,
                               "ms_per_launch": tick_ms, "bytes_per_launch": tree_bytes(d, C) / n_ticks},
             "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, weights)
+            out["cpu_baseline"] = cpu_baseline(cfg, weights if cfg.board_size == 11 else None)
         print(json.dumps(out), flush=True)
     sp.close()
     if world > 1:

@@ -1,0 +1,101 @@
+"""Config-1 path on the GPU box: Player(training=False, pv_fn=net.eval) with the shipped alphaFive-6960
+weights through the HIP net, driven like self_play.py:79-106 — and the C oracle fed by the SAME
+evaluator (one leaf at a time), so visit counts and moves must agree bit for bit even with the
+real network."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, make_cfg
+
+pytestmark = pytest.mark.gpu
+W = os.path.join(GOLDEN, "alphaFive-6960.weights.npz")
+
+
+def _hip_eval():
+    import torch
+    from alphafive_amd.network import ResNet
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    pv = net.select_backend("hip")
+
+    def eval_np(x):                      # numpy float32[B,3,S,S] -> (prob, value) numpy, like ResNet.eval
+        p, v = pv(torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda())
+        return p.cpu().numpy().copy(), v.cpu().numpy().copy()
+    return net, eval_np
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_player_with_real_net_matches_oracle_through_same_evaluator(training):
+    from alphafive_amd.player import Player
+    from alphafive_amd import utils
+    net, eval_np = _hip_eval()
+    cfg = make_cfg(simulation_per_step=120, upper_simulation_per_step=160)
+    pl = Player(cfg, training=training, pv_fn=eval_np, seed=3, game_id=1)
+    orc = oracle.OraclePlayer(cfg, training=training, rng_mode=oracle.RNG_PHILOX, seed=3, game_id=1, pv_fn=eval_np)
+    state, over, ply = pl.get_init_state(), False, 0
+    last = None
+    while not over and ply < 8:
+        la = last if training else None           # self_play.py:95-97 passes None as last_action
+        pol, act = pl.get_action(state, last_action=la)
+        opol, oact, ovis = orc.get_action(state, la)
+        assert (pl.last_visits == ovis).all(), f"ply {ply}: visit counts differ"
+        assert act == oact
+        if training:
+            assert (pol.view(np.uint32) == opol.view(np.uint32)).all()
+        else:
+            assert pol is None and opol is None
+        board = utils.step(utils.state_to_board(state, 11), act)
+        state = utils.board_to_state(board)
+        over, _ = utils.is_game_over(board, 5)
+        last, ply = act, ply + 1
+    assert len(pl.tree) == orc.tree_size()
+    pl.close()
+
+
+def test_headless_self_play_loop_finishes_a_game():
+    from alphafive_amd import self_play
+    from alphafive_amd.network import ResNet
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    cfg = make_cfg(simulation_per_step=60, upper_simulation_per_step=80)
+    moves, value, dt = self_play.play(cfg, net, seed=0, verbose=False)
+    assert 9 <= len(moves) <= 121 and value in (-1.0, 0.0)
+    assert len(set(moves)) == len(moves)          # no cell played twice
+
+
+def test_selfplay_engine_with_real_net_produces_valid_episodes():
+    import torch
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.network import ResNet
+    from alphafive_amd import utils
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    cfg = make_cfg(simulation_per_step=40, upper_simulation_per_step=60)
+    sp = SelfPlayEngine(cfg, 256, net.select_backend("auto"), device=0, seed=9)
+    eps = []
+    for _ in range(60):
+        sp.run_ticks(100)
+        sp.check()
+        eps += sp.pop_episodes(256)
+        if len(eps) >= 64:
+            break
+    assert len(eps) >= 64
+    for rec, result in eps[:64]:
+        T = len(rec)
+        assert 9 <= T <= 121 and result in (-1, 0, 1)
+        board = np.zeros((11, 11), np.int8)
+        for t, (s, p, la, v, w) in enumerate(rec):
+            assert s == utils.board_to_state(board)          # states chain by the recorded moves
+            assert p.shape == (11, 11) and abs(float(p.sum()) - 1.0) < 1e-4 and isinstance(w, np.float32)
+            assert (p[board != 0] == 0).all()
+            if t + 1 < T:
+                nxt = rec[t + 1][2]
+                board = utils.step(board, nxt)
+        if result != 0:
+            assert rec[-1][3] == 1.0 and (result == 1) == (T % 2 == 1)     # last mover won (player.py:74-76)
+    ct = sp.counters()
+    assert ct["terminals"] > 0 and ct["episodes"] >= 64
+    sp.close()
