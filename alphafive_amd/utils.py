@@ -114,3 +114,132 @@ def construct_weights(length, gamma=0.95):
 def softmax(x):
     e = np.exp(x - np.max(x))
     return e / np.sum(e)
+
+
+class RandomStack(object):
+    """Replay buffer with the reference's behaviour and call surface (utils.py:14-146): FIFO of
+    per-position 5-tuples `(state, policy[S,S], last_action, value, weight)`; push() rejects short
+    games at random (utils.py:81), duplicates episodes of the under-represented winner
+    (utils.py:86-100) and evicts from the front with partial-episode bookkeeping (utils.py:101-115);
+    get_data() samples without replacement and applies one of the 8 board symmetries, remapping
+    last_action (utils.py:118-146).  Draws from the same global streams in the same order as the
+    reference (`random.random`, `np.random.choice`, `random.choice`), so a seeded run is reproducible
+    against it (tests/test_host_utils.py)."""
+
+    def __init__(self, board_size, length=2000):
+        import time as _time
+        self.data = []
+        self.board_size = board_size
+        self.length = length
+        self.white_win = 0
+        self.black_win = 0
+        self.data_len = []
+        self.result = []
+        self.total_length = 0
+        self.num = 0
+        self.time = _time.time()
+        self.self_play_black_win = 0
+        self.self_play_white_win = 0
+
+    # ---- persistence: same three pickles as utils.py:29-57 ----
+    _FILES = (("data", "data"), ("data_len", "data_len"), ("result", "result"))
+
+    def save(self, s=""):
+        import pickle
+        for attr, stem in self._FILES:
+            with open(f"data_buffer/{stem}{s}.pkl", "wb") as f:
+                pickle.dump(getattr(self, attr), f)
+
+    def load(self, s=""):
+        import pickle
+        for attr, stem in self._FILES:
+            with open(f"data_buffer/{stem}{s}.pkl", "rb") as f:
+                setattr(self, attr, pickle.load(f))
+        self.white_win = self.result.count(WHITE_WIN)
+        self.black_win = self.result.count(BLACK_WIN)
+        print("load data successfully, with length %d" % len(self.data))
+        print("black: white = %d: %d in the memory" % (self.black_win, self.white_win))
+
+    def isEmpty(self):
+        return len(self.data) == 0
+
+    def is_full(self):
+        return len(self.data) >= self.length
+
+    def _append_episode(self, data, result):
+        self.data.extend(data)
+        self.data_len.append(len(data))
+        self.result.append(result)
+
+    def push(self, data, result):
+        import random as _random
+        import time as _time
+        n = len(data)
+        self.total_length += n
+        self.num += 1
+        if result == BLACK_WIN:
+            self.self_play_black_win += 1
+        elif result == WHITE_WIN:
+            self.self_play_white_win += 1
+        if self.total_length >= 100:
+            now = _time.time()
+            print("black: white = %d: %d in the memory, avg_length: %0.1f avg: %0.3fs per piece" % (
+                self.black_win, self.white_win, self.total_length / self.num, (now - self.time) / self.total_length))
+            print("self-play black: %d, white: %d" % (self.self_play_black_win, self.self_play_white_win))
+            self.total_length = self.num = 0
+            self.time = now
+        # short games are dropped with probability -0.0682*T + 1.364 (T=9: 0.75, T>=20: 0)
+        if _random.random() <= -0.0682 * n + 1.364:
+            return False
+        self._append_episode(data, result)
+        if result == BLACK_WIN:
+            self.black_win += 1
+            if _random.random() < (self.white_win - self.black_win) / (self.black_win * 1.3):
+                self._append_episode(data, result)
+                self.black_win += 1
+        elif result == WHITE_WIN:
+            self.white_win += 1
+            if _random.random() < (self.black_win - self.white_win) / (self.white_win * 1.02):
+                self._append_episode(data, result)
+                self.white_win += 1
+        beyond = len(self.data) - self.length
+        if beyond > 0:
+            del self.data[:beyond]
+            while beyond >= self.data_len[0]:           # whole episodes fall out of the front
+                beyond -= self.data_len.pop(0)
+                gone = self.result.pop(0)
+                if gone == BLACK_WIN:
+                    self.black_win -= 1
+                elif gone == WHITE_WIN:
+                    self.white_win -= 1
+            self.data_len[0] -= beyond                  # the front episode is cut short
+        return True
+
+    def get_data(self, batch_size=1):
+        import random as _random
+        S = self.board_size
+        num = min(batch_size, len(self.data))
+        idx = np.random.choice(len(self.data), size=num, replace=False)
+        boards = np.empty((num, 3, S, S), dtype=np.float32)
+        weights = np.empty((num,), dtype=np.float32)
+        values = np.empty((num,), dtype=np.float32)
+        policies = np.empty((num, S, S), dtype=np.float32)
+        for i, ix in enumerate(idx):
+            state, p, la, v, w = self.data[ix]
+            board = state_to_board(state, S)
+            k = np.random.choice([0, 1, 2, 3])          # quarter turns
+            board = np.rot90(board, k=k, axes=(0, 1))
+            p = np.rot90(p, k=k, axes=(0, 1))
+            if la is not None:
+                for _ in range(int(k)):                 # one quarter turn: (i, j) -> (S-1-j, i)
+                    la = (S - 1 - la[1], la[0])
+            if _random.choice([1, 2]) == 1:             # vertical flip
+                board = np.flip(board, axis=0)
+                p = np.flip(p, axis=0)
+                if la is not None:
+                    la = (S - 1 - la[0], la[1])
+            boards[i] = board_to_inputs(board, last_action=la)
+            weights[i] = w
+            values[i] = v
+            policies[i] = p
+        return boards, weights, values, policies.reshape((num, S * S))

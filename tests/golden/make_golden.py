@@ -224,8 +224,62 @@ def gen_run(path, S, goal, sims, upper, seed, salt, peak, episodes):
     np.savez_compressed(path, **out)
 
 
+def gen_randomstack(path):
+    """utils.RandomStack (utils.py:14-146): seeded pushes of synthetic episodes, then seeded get_data."""
+    import io
+    import contextlib
+    S = 7
+    rng = np.random.RandomState(5)
+    episodes = []
+    for e in range(60):
+        T = int(rng.randint(9, 40))
+        recs = []
+        board = np.zeros((S, S), np.int8)
+        last = None
+        for t in range(T):
+            empt = refutils.get_legal_actions(board)
+            a = empt[rng.randint(len(empt))]
+            pol = rng.rand(S, S).astype(np.float32)
+            pol /= pol.sum()
+            recs.append((refutils.board_to_state(board), pol, last, float((-1.0) ** (T - t)), np.float32(rng.rand() + 0.5)))
+            board = refutils.step(board, a)
+            last = a
+        episodes.append((recs, int(rng.choice([1, -1, 0], p=[0.55, 0.4, 0.05]))))
+    np.random.seed(21)
+    random.seed(21)
+    st = refutils.RandomStack(board_size=S, length=400)
+    accepted = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for recs, res in episodes:
+            accepted.append(st.push(recs, res))
+    out = dict(S=np.asarray(S), length=np.asarray(400), accepted=np.array(accepted),
+               data_len=np.array(st.data_len), result=np.array(st.result), n_data=np.asarray(len(st.data)),
+               black_win=np.asarray(st.black_win), white_win=np.asarray(st.white_win),
+               first_state=np.array(st.data[0][0]), last_state=np.array(st.data[-1][0]))
+    for e, (recs, res) in enumerate(episodes):
+        out[f"ep{e}_states"] = np.array([r[0] for r in recs])
+        out[f"ep{e}_policies"] = np.array([r[1] for r in recs])
+        out[f"ep{e}_lasts"] = np.array([-1 if r[2] is None else r[2][0] * S + r[2][1] for r in recs], np.int32)
+        out[f"ep{e}_values"] = np.array([r[3] for r in recs])
+        out[f"ep{e}_weights"] = np.array([r[4] for r in recs], np.float32)
+        out[f"ep{e}_result"] = np.asarray(res)
+    out["n_episodes"] = np.asarray(len(episodes))
+    for b in range(3):
+        boards, weights, values, policies = st.get_data(batch_size=48)
+        out[f"batch{b}_boards"], out[f"batch{b}_weights"] = boards, weights
+        out[f"batch{b}_values"], out[f"batch{b}_policies"] = values, policies
+    out["np_next"] = np.asarray(int(np.random.randint(0, 2 ** 32, dtype=np.uint64)))
+    out["py_next"] = np.asarray(random.getrandbits(32))
+    np.savez_compressed(path, **out)
+    print("randomstack:", sum(accepted), "accepted of", len(episodes), "buffer", len(st.data))
+
+
 def main():
+    if "--only-randomstack" in sys.argv:
+        gen_randomstack(os.path.join(HERE, "randomstack.npz"))
+        return
     gen_rules(os.path.join(HERE, "rules.npz"))
+    gen_randomstack(os.path.join(HERE, "randomstack.npz"))
     G = lambda name: os.path.join(HERE, name)  # noqa: E731
     # training mode, forced root visits not exhausted (sims < 2L) and exhausted (sims > 2L)
     gen_mcts(G("mcts_s11_train_a.npz"), 11, 5, 60, 80, True, 0, 1234, 0, 12)

@@ -57,3 +57,38 @@ def test_episode_assembly_matches_run_goldens():
 def _key(state, S):
     from alphafive_amd import engine as eng
     return eng.state_to_key(state, S)
+
+
+def test_randomstack_matches_reference_under_seeded_streams():
+    """alphafive_amd.utils.RandomStack vs goldens recorded from utils.RandomStack (utils.py:14-146):
+    same accept/duplicate/evict decisions and the same augmented batches, consuming np.random and
+    random in the same order."""
+    import contextlib
+    import io
+    import random
+    z = dict(np.load(os.path.join(GOLDEN, "randomstack.npz")))
+    S = int(z["S"])
+    np.random.seed(21)
+    random.seed(21)
+    st = utils.RandomStack(board_size=S, length=int(z["length"]))
+    accepted = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for e in range(int(z["n_episodes"])):
+            recs = []
+            for t in range(len(z[f"ep{e}_states"])):
+                la = int(z[f"ep{e}_lasts"][t])
+                recs.append((str(z[f"ep{e}_states"][t]), z[f"ep{e}_policies"][t], None if la < 0 else (la // S, la % S),
+                             float(z[f"ep{e}_values"][t]), np.float32(z[f"ep{e}_weights"][t])))
+            accepted.append(st.push(recs, int(z[f"ep{e}_result"])))
+    assert accepted == list(z["accepted"])
+    assert st.data_len == list(z["data_len"]) and st.result == list(z["result"])
+    assert len(st.data) == int(z["n_data"]) and st.is_full() == (len(st.data) >= st.length)
+    assert (st.black_win, st.white_win) == (int(z["black_win"]), int(z["white_win"]))
+    assert st.data[0][0] == str(z["first_state"]) and st.data[-1][0] == str(z["last_state"])
+    for b in range(3):
+        boards, weights, values, policies = st.get_data(batch_size=48)
+        assert (boards == z[f"batch{b}_boards"]).all() and (weights == z[f"batch{b}_weights"]).all()
+        assert (values == z[f"batch{b}_values"]).all() and (policies == z[f"batch{b}_policies"]).all()
+        assert boards.dtype == np.float32 and policies.shape == (48, S * S)
+    assert int(np.random.randint(0, 2 ** 32, dtype=np.uint64)) == int(z["np_next"])
+    assert random.getrandbits(32) == int(z["py_next"])
