@@ -209,13 +209,18 @@ struct WinoArgs {
     int cin, cin2, cout, ntiles, T, S, WP, PP;
 };
 
+// LDSU = true: the U stream of the 3x3 segment is shared by the workgroup through LDS (A.u in the
+// slice layout of pack_wino_lds); false: every wave loads its own U fragments (A.u from pack_wino).
+template <bool LDSU, int ABL = 0>   // ABL (profiling only): 1 = no operand loads in the 3x3 loop, 2 = no input transform
 __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
+    __shared__ float4 su[LDSU ? 3 * 4 * 256 : 1];       // 3 buffers x 4 pair slices x 4 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, kh = lane >> 5;
     const int nct = A.cout >> 5;
     const int ct = blockIdx.x % nct;
     const int tb = (blockIdx.x / nct) * 4 + wave;
-    if (tb * 32 >= A.ntiles) return;
+    const bool wave_live = tb * 32 < A.ntiles;           // (a dead wave still helps stage U and hits the barriers)
+    if (!LDSU && !wave_live) return;
     const int q = tb * 32 + col;
     const bool valid = q < A.ntiles;
     const int qq = valid ? q : 0;
@@ -232,34 +237,38 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) M[x][r] = 0.0f;
 
+    float bias_r[16];                                    // requested now, consumed in the epilogue
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = A.bias[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
     const uint32_t wlane = (uint32_t)(kh * cout + ct * 32 + col);
-    // Both k loops run a 4-deep register ring: the operands of phase p+3 are requested while phase p
-    // computes (16 MFMAs = 1024 cycles per phase => >= 3072 cycles for a load to land), and the 8-12
-    // wide loads + the transform adds of a phase are spread between its MFMAs by sched_group_barrier.
-    {   // ---- 3x3 segment: phase = one cin pair (16 MFMAs) ----
+    // k loops: operands ride a 4-deep register ring — the loads of phase p+3 are requested while phase p
+    // computes (16 MFMAs = 1024 cycles per phase => >= 3072 cycles to land) — and the wide loads + the
+    // transform adds of a phase are spread between its MFMAs by sched_group_barrier.
+    if constexpr (ABL != 3) {   // ---- 3x3 segment: phase = one cin pair (16 MFMAs) ----  (ABL 3: epilogue only)
         const char* __restrict__ inb = reinterpret_cast<const char*>(A.in);
-        const char* __restrict__ ub = reinterpret_cast<const char*>(A.u);
         const uint32_t boff = (uint32_t)(pos * A.cin * PP + poff0 + kh * PP) * 4u;
-        const uint32_t woff = wlane * 64u;               // 16 floats per (kh, cout)
-        const int npairs = A.cin / 2;                    // multiple of 8
-        // activations (first touch comes from HBM / Infinity Cache) ride an 8-deep ring, weights (L2) a 4-deep one
-        f4u d0[4], d1[4], d2[4], d3[4], d4[4], d5[4], d6[4], d7[4];
-        float4 u0[4], u1[4], u2[4], u3[4];
+        const int npairs = A.cin / 2;                    // multiple of 4
+        f4u d0[4] = {}, d1[4] = {}, d2[4] = {}, d3[4] = {};
         auto load_d = [&](int c, f4u (&d)[4]) {
+            if constexpr (ABL == 1) return;
             c = c < npairs ? c : npairs - 1;             // tail: harmless re-load instead of a branch
             const char* ip = inb + (ptrdiff_t)(2 * c) * PP * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)                  // one patch row = 4 consecutive floats (4-byte aligned)
                 d[r] = *reinterpret_cast<const f4u*>(ip + (ptrdiff_t)(r * WP) * 4 + (size_t)boff);
         };
-        auto load_u = [&](int c, float4 (&u)[4]) {
-            c = c < npairs ? c : npairs - 1;
-            const char* up = ub + (size_t)c * 2 * cout * 64;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) u[r] = *reinterpret_cast<const float4*>(up + (size_t)r * 16 + (size_t)woff);
-        };
         auto compute_pair = [&](f4u (&d)[4], float4 (&u)[4]) {
             float t[16], v[16];
+            if constexpr (ABL == 2) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    M[4 * x + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].x, d[x][0], M[4 * x + 0], 0, 0, 0);
+                    M[4 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].y, d[x][1], M[4 * x + 1], 0, 0, 0);
+                    M[4 * x + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].z, d[x][2], M[4 * x + 2], 0, 0, 0);
+                    M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, d[x][3], M[4 * x + 3], 0, 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                // t = B^T d
                 t[0 + s] = d[0][s] - d[2][s];
@@ -282,35 +291,99 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
                 M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, v[4 * x + 3], M[4 * x + 3], 0, 0, 0);
             }
         };
-        auto phase = [&](int c, f4u (&dl)[4], float4 (&ul)[4], f4u (&dc)[4], float4 (&uc)[4]) {
-            load_d(c + 7, dl);
-            load_u(c + 3, ul);
-            compute_pair(dc, uc);
+        if constexpr (!LDSU) {
+            const char* __restrict__ ub = reinterpret_cast<const char*>(A.u);
+            const uint32_t woff = wlane * 64u;           // 16 floats per (kh, cout)
+            float4 u0[4] = {}, u1[4] = {}, u2[4] = {}, u3[4] = {};
+            auto load_u = [&](int c, float4 (&u)[4]) {
+                if constexpr (ABL == 1) return;
+                c = c < npairs ? c : npairs - 1;
+                const char* up = ub + (size_t)c * 2 * cout * 64;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
+                for (int r = 0; r < 4; ++r) u[r] = *reinterpret_cast<const float4*>(up + (size_t)r * 16 + (size_t)woff);
+            };
+            auto phase = [&](int c_load, f4u (&dl)[4], float4 (&ul)[4], f4u (&dc)[4], float4 (&uc)[4]) {
+                load_d(c_load, dl);
+                load_u(c_load, ul);
+                compute_pair(dc, uc);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            load_d(0, d0); load_u(0, u0);
+            load_d(1, d1); load_u(1, u1);
+            load_d(2, d2); load_u(2, u2);
             __builtin_amdgcn_sched_barrier(0);
-        };
-        load_d(0, d0); load_d(1, d1); load_d(2, d2); load_d(3, d3); load_d(4, d4); load_d(5, d5); load_d(6, d6);
-        load_u(0, u0); load_u(1, u1); load_u(2, u2);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int c = 0; c < npairs; c += 8) {
-            phase(c + 0, d7, u3, d0, u0);
-            phase(c + 1, d0, u0, d1, u1);
-            phase(c + 2, d1, u1, d2, u2);
-            phase(c + 3, d2, u2, d3, u3);
-            phase(c + 4, d3, u3, d4, u0);
-            phase(c + 5, d4, u0, d5, u1);
-            phase(c + 6, d5, u1, d6, u2);
-            phase(c + 7, d6, u2, d7, u3);
+            for (int c = 0; c < npairs; c += 4) {
+                phase(c + 3, d3, u3, d0, u0);
+                phase(c + 4, d0, u0, d1, u1);
+                phase(c + 5, d1, u1, d2, u2);
+                phase(c + 6, d2, u2, d3, u3);
+            }
+        } else {
+            // U through LDS: a (pair, ct) slice is 4 KB laid out [x][lane][4] (pack_wino_lds), i.e. exactly
+            // one float4 per thread of the workgroup; thread t of wave w stages quad x = w.  Chunks of 4
+            // pairs: chunk k+1 is written to buffer (k+1)%3 at the start of chunk k from registers whose
+            // global loads were issued during chunk k-1 (4096 cycles earlier); one workgroup barrier per
+            // chunk (after phase 1) makes it visible before phase 3 prefetches the next chunk's first pair.
+            const float4* __restrict__ ug = reinterpret_cast<const float4*>(A.u) + (size_t)ct * 256 + threadIdx.x;
+            const size_t ustride = (size_t)nct * 256;    // float4s between consecutive pairs
+            const int nchunks = npairs / 4;
+            auto gload = [&](int c) { c = c < npairs ? c : npairs - 1; return ug[(size_t)c * ustride]; };
+            auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+            float4 G[4], uA[4], uB[4];
+            auto lds_read = [&](int buf, int slot, float4 (&u)[4]) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) u[x] = su[(buf * 4 + slot) * 256 + x * 64 + lane];
+            };
+#pragma unroll
+            for (int p = 0; p < 4; ++p) su[(0 * 4 + p) * 256 + threadIdx.x] = gload(p);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) G[p] = gload(4 + p);
+            load_d(0, d0); load_d(1, d1); load_d(2, d2);
+            lds_barrier();
+            lds_read(0, 0, uA);
+            __builtin_amdgcn_sched_barrier(0);
+            auto phase = [&](int c_load, f4u (&dl)[4], float4& g, int g_pair, int rbuf, int rslot, float4 (&un)[4],
+                             f4u (&dc)[4], float4 (&uc)[4]) {
+                load_d(c_load, dl);
+                g = gload(g_pair);
+                lds_read(rbuf, rslot, un);
+                compute_pair(dc, uc);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int bcur = 0;                                // buffer holding chunk k
+            for (int k = 0; k < nchunks; ++k) {
+                const int bnext = bcur == 2 ? 0 : bcur + 1;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) su[(bnext * 4 + p) * 256 + threadIdx.x] = G[p];   // chunk k+1 -> LDS
+                const int c = 4 * k;
+                phase(c + 3, d3, G[0], c + 8, bcur, 1, uB, d0, uA);
+                phase(c + 4, d0, G[1], c + 9, bcur, 2, uA, d1, uB);
+                lds_barrier();
+                phase(c + 5, d1, G[2], c + 10, bcur, 3, uB, d2, uA);
+                phase(c + 6, d2, G[3], c + 11, bnext, 0, uA, d3, uB);
+                bcur = bnext;
+            }
         }
     }
-    if (A.in2) {   // ---- 1x1 projection segment: phase = 4 cin pairs (16 MFMAs) ----
+    if (!wave_live) return;
+    if (ABL != 3 && A.in2) {   // ---- 1x1 projection segment: phase = 4 cin pairs (16 MFMAs) ----
         const char* __restrict__ inb = reinterpret_cast<const char*>(A.in2);
         const char* __restrict__ ub = reinterpret_cast<const char*>(A.u2);
         const uint32_t boff = (uint32_t)(pos * A.cin2 * PP + poff0 + kh * PP + WP + 1) * 4u;   // patch centre (1,1)
@@ -364,25 +437,32 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
         }
     }
     // ---- output transform Y = A^T M A, bias, ELU, store the 2x2 tile ----
-    const bool ok0y = 2 * ty < A.S, ok1y = 2 * ty + 1 < A.S, ok0x = 2 * tx < A.S, ok1x = 2 * tx + 1 < A.S;
+    // (bias values were requested before the k loops; each tile row goes out as one 8-byte store, so the
+    // lanes of a board row write one contiguous run)
+    const bool ok1y = 2 * ty + 1 < A.S, ok1x = 2 * tx + 1 < A.S;      // rows/cols 2t are always inside the board
+    float* const obase = A.out + (size_t)pos * cout * PP + poff0 + WP + 1;  // output pixel (2ty, 2tx) of cout 0
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const float bv = A.bias[co];
+        const float bv = bias_r[r];
         float s0[4], s1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s0[j] = M[0 + j][r] + M[4 + j][r] + M[8 + j][r];
             s1[j] = M[4 + j][r] - M[8 + j][r] - M[12 + j][r];
         }
-        const float y00 = elu1(s0[0] + s0[1] + s0[2] + bv), y01 = elu1(s0[1] - s0[2] - s0[3] + bv);
-        const float y10 = elu1(s1[0] + s1[1] + s1[2] + bv), y11 = elu1(s1[1] - s1[2] - s1[3] + bv);
-        float* o = A.out + (size_t)(pos * cout + co) * PP + poff0 + WP + 1;     // output pixel (2ty, 2tx)
+        f2u y0, y1;
+        y0[0] = elu1(s0[0] + s0[1] + s0[2] + bv); y0[1] = elu1(s0[1] - s0[2] - s0[3] + bv);
+        y1[0] = elu1(s1[0] + s1[1] + s1[2] + bv); y1[1] = elu1(s1[1] - s1[2] - s1[3] + bv);
+        float* o = obase + (size_t)co * PP;
         if (valid) {
-            if (ok0y && ok0x) o[0] = y00;
-            if (ok0y && ok1x) o[1] = y01;
-            if (ok1y && ok0x) o[WP] = y10;
-            if (ok1y && ok1x) o[WP + 1] = y11;
+            if (ok1x) {
+                *reinterpret_cast<f2u*>(o) = y0;
+                if (ok1y) *reinterpret_cast<f2u*>(o + WP) = y1;
+            } else {
+                o[0] = y0[0];
+                if (ok1y) o[WP] = y1[0];
+            }
         }
     }
 }
@@ -560,7 +640,7 @@ struct af_net {
     // device weights
     float *stem_w, *stem_b;
     float *conv1_w[5], *conv1_b[5], *conv2_w[5], *res_w[5], *sum_b[5];
-    float *wino1_u[5], *wino2_u[5], *winor_u[5];
+    float *wino1_u[5], *wino2_u[5], *winor_u[5], *wino1_ul[5], *wino2_ul[5];
     int T;
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> events;
@@ -623,6 +703,20 @@ static std::vector<float> pack_wino(const std::vector<float>& w, int taps, int c
                 out[((((size_t)(c / 2) * 2) + (c & 1)) * cout + co) * npos + p] = (float)u;
             }
         }
+    return out;
+}
+// U for the LDS path: a (pair c, cout tile ct) slice = 1024 floats [x][lane = kh*32+col][e],
+// (xi,nu) = 4x+e, cin = 2c+kh, cout = ct*32+col; slices ordered [c][ct].
+static std::vector<float> pack_wino_lds(const std::vector<float>& w, int cin, int cout) {
+    const std::vector<float> u = pack_wino(w, 9, cin, cout);        // [c/2][2][cout][16]
+    const int nct = cout / 32;
+    std::vector<float> out(u.size());
+    for (int c = 0; c < cin / 2; ++c)
+        for (int kh = 0; kh < 2; ++kh)
+            for (int co = 0; co < cout; ++co)
+                for (int p = 0; p < 16; ++p)
+                    out[(((size_t)c * nct + co / 32) * 4 + p / 4) * 256 + (kh * 32 + co % 32) * 4 + p % 4] =
+                        u[(((size_t)c * 2 + kh) * cout + co) * 16 + p];
     return out;
 }
 static std::vector<float> pad_bias(const std::vector<float>& a, const std::vector<float>* b, int cout) {
@@ -706,6 +800,8 @@ int af_net_finalize(af_net* n) {
         UP(sum_b[i], pad_bias(V[s + "_conv2/bias"], &V[s + "_res/bias"], b.cout));
         UP(wino1_u[i], pack_wino(V[s + "_conv1/kernel"], 9, b.cin, b.cout));
         UP(wino2_u[i], pack_wino(V[s + "_conv2/kernel"], 9, b.cout, b.cout));
+        UP(wino1_ul[i], pack_wino_lds(V[s + "_conv1/kernel"], b.cin, b.cout));
+        UP(wino2_ul[i], pack_wino_lds(V[s + "_conv2/kernel"], b.cout, b.cout));
         UP(winor_u[i], pack_wino(V[s + "_res/kernel"], 1, b.cin, b.cout));
     }
     UP(vc_w, V["value/conv/kernel"]); UP(vc_b, V["value/conv/bias"]); UP(v1_w, V["value/fc1/kernel"]);
@@ -728,7 +824,8 @@ int af_net_finalize(af_net* n) {
 
 // tile-shape selection per cout width (tuning knob, see af_net_tune): index = cout_pad/32 - 1 (.. 3 for 128)
 static int g_shape[4] = {0, 0, 0, 0};
-static int g_wino = 1;   // 1: 3x3 layers through af_conv_wino (default); 0: direct af_conv_mfma
+static int g_abl = 0;    // profiling: ablation variant of af_conv_wino<false>
+static int g_wino = 1;   // 1: af_conv_wino<false> (default); 2: af_conv_wino<true> (U through LDS: measured 6 % slower); 0: direct af_conv_mfma
 
 static void launch_wino(hipStream_t st, const af_net* n, int batch, const float* in, const float* u, int cin,
                         const float* in2, const float* u2, int cin2, const float* bias, float* out, int cout) {
@@ -737,7 +834,11 @@ static void launch_wino(hipStream_t st, const af_net* n, int batch, const float*
     a.cin = cin; a.cin2 = cin2; a.cout = cout; a.T = n->T; a.S = n->S; a.WP = n->WP; a.PP = n->PP;
     a.ntiles = batch * n->T * n->T;
     const int ntb = (a.ntiles + 31) / 32;
-    hipLaunchKernelGGL(af_conv_wino, dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
+    if (g_wino == 2) hipLaunchKernelGGL((af_conv_wino<true, 0>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 1) hipLaunchKernelGGL((af_conv_wino<false, 1>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 3) hipLaunchKernelGGL((af_conv_wino<false, 3>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 2) hipLaunchKernelGGL((af_conv_wino<false, 2>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((af_conv_wino<false, 0>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
 }
 
 template <int NT, int MT, int MINW>
@@ -794,8 +895,10 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
         const Block& b = kBlocks[i];
         if (g_wino) {
             // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
-            launch_wino(st, n, batch, block_in[i], n->wino1_u[i], b.cin, nullptr, nullptr, 0, n->conv1_b[i], g[i], b.cout);
-            launch_wino(st, n, batch, g[i], n->wino2_u[i], b.cout, block_in[i], n->winor_u[i], b.cin, n->sum_b[i], o[i], b.cout);
+            launch_wino(st, n, batch, block_in[i], g_wino == 2 ? n->wino1_ul[i] : n->wino1_u[i], b.cin, nullptr, nullptr, 0,
+                        n->conv1_b[i], g[i], b.cout);
+            launch_wino(st, n, batch, g[i], g_wino == 2 ? n->wino2_ul[i] : n->wino2_u[i], b.cout, block_in[i], n->winor_u[i], b.cin,
+                        n->sum_b[i], o[i], b.cout);
         } else {
             ConvArgs a;
             memset(&a, 0, sizeof(a));
@@ -864,7 +967,8 @@ int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, 
 }
 
 int af_net_tune(int32_t cout_pad, int32_t shape) {
-    if (cout_pad == 0) { g_wino = shape ? 1 : 0; return AF_NET_OK; }     // 0: select Winograd (1) / direct (0)
+    if (cout_pad == 0) { g_wino = shape; return AF_NET_OK; }     // 0: conv path (2 Winograd+LDS, 1 Winograd, 0 direct)
+    if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)
     if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
     if (cout_pad == 2) { g_subbatch = shape; return AF_NET_OK; }                     // 2: sub-batch size (0 = batch/streams)
     if (cout_pad != 32 && cout_pad != 64 && cout_pad != 128) return AF_NET_ERR_ARG;

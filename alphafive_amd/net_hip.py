@@ -101,3 +101,11 @@ def roofline_info():
             "kernel": "af_net_forward = af_stem_conv + 10x af_conv_wino + af_value_head + af_policy_head "
                       "(whole forward timed; af_conv_wino carries 97 % of the algorithmic FLOPs; achieved = "
                       "direct-convolution FLOPs / time, the MFMAs issued are 2.25x fewer on the 3x3 layers)"}
+
+
+def tune(key, value):
+    """Benchmark knob (af_net_tune): key 32/64/128 = tile shape of the direct kernel for that width;
+    key 0 = conv path (2 Winograd + LDS-shared U, 1 Winograd, 0 direct); key 1/2 = sub-batch streams/size;
+    key 3 = ablation variant of the Winograd kernel (profiling only)."""
+    lib().af_net_tune.argtypes = [C.c_int32, C.c_int32]
+    _check(lib().af_net_tune(key, value), "af_net_tune")
