@@ -467,6 +467,10 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
     }
 }
 
+// (r1 experiment, removed: af_conv_wino2 split the 16 Winograd-domain accumulators over a wave pair —
+// 128 AGPRs per wave, two waves per SIMD, partial outputs swapped through LDS.  Correct, but hipcc spilled
+// 288 B/lane at the 256-register budget and the pair doubles the patch loads: 4.94 ms vs 3.96 ms.)
+
 // stem: conv 5x5 SAME 3->32 + ELU (network.py:63), one block per position, one thread per pixel
 __global__ __launch_bounds__(256) void af_stem_conv(const float* __restrict__ planes, const float* __restrict__ w /*[75][32]*/,
                                                     const float* __restrict__ bias, float* __restrict__ out, int S, int WP, int PP) {
