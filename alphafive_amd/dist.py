@@ -79,7 +79,7 @@ def gather_episodes(eps, world, rank, device, game_offset=None):
 
 def broadcast_weights(net, src=0):
     """Replicate rank `src`'s network variables on every rank (ncclBroadcast per tensor)."""
-    dev = net.device if net.device.type == "cuda" else torch.device("cpu")
+    dev = net.device if (net.device.type == "cuda" and dist.get_backend() == "nccl") else torch.device("cpu")
     new = {}
     for name in sorted(net.variables):
         t = torch.from_numpy(net.variables[name]).to(dev)

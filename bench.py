@@ -101,11 +101,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    # AF_BENCH_SHARE_GPU=1 (test hook): all ranks share device 0 and talk over gloo, so the N>1 code path
+    # can be exercised end to end on a 1-GPU box; the driver's runs use one GPU per rank over RCCL.
+    share = os.environ.get("AF_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    comm_dev = torch.device("cpu") if share else dev
 
     from alphafive_amd.engine import SelfPlayEngine
     from alphafive_amd.network import ResNet
@@ -152,7 +161,7 @@ def main():
                 break
         sp.check()
         # finished episodes -> rank 0 (RCCL gather over xGMI when world > 1)
-        eps = afdist.gather_episodes(sp.pop_raw(cap=1024), world, rank, dev)
+        eps = afdist.gather_episodes(sp.pop_raw(cap=1024), world, rank, comm_dev, game_offset=rank * G)
         if rank == 0:
             gathered["episodes"] += len(eps)
             gathered["plies"] += sum(e["T"] for e in eps)
@@ -181,8 +190,8 @@ def main():
     ct1 = sp.counters()
     plies = sp.progress()[0] - p0
 
-    tot = torch.tensor([float(plies)], device=dev, dtype=torch.float64)
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    tot = torch.tensor([float(plies)], device=comm_dev, dtype=torch.float64)
+    tmax = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
