@@ -573,12 +573,18 @@ __global__ __launch_bounds__(256) void af_policy_head(const float* __restrict__ 
         }
     }
     __syncthreads();
+    // dense layer: thread (ks, tj) accumulates logit tj over the ks-th slice of the 16*HW inputs for PPB
+    // positions at once (weights streamed once per block); slices are summed through LDS in fixed order
+    const int JW = HW <= 128 ? 128 : 256, KS = blockDim.x / JW;
+    const int ks = t / JW, tj = t - ks * JW;
+    const bool owner = ks == 0 && tj < HW;
     float acc[PPB];
-    const int j = t < HW ? t : HW - 1;
+    const int j = tj < HW ? tj : HW - 1;
 #pragma unroll
-    for (int p = 0; p < PPB; ++p) acc[p] = bf[j];
+    for (int p = 0; p < PPB; ++p) acc[p] = ks == 0 ? bf[j] : 0.0f;
+    const int K = 16 * HW, k0 = ks * (K / KS), k1 = ks == KS - 1 ? K : k0 + K / KS;
 #pragma unroll 8
-    for (int k = 0; k < 16 * HW; ++k) {
+    for (int k = k0; k < k1; ++k) {
         const float wv = wf[(size_t)k * HW + j];
         const float4* xr = reinterpret_cast<const float4*>(sh + (size_t)k * PPB);
 #pragma unroll
@@ -588,12 +594,25 @@ __global__ __launch_bounds__(256) void af_policy_head(const float* __restrict__ 
             acc[4 * q + 2] = fmaf(xv.z, wv, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(xv.w, wv, acc[4 * q + 3]);
         }
     }
+    if (KS > 1) {
+        __syncthreads();                                  // everyone is done reading sh: reuse it for the partials
+        if (ks > 0) {
+#pragma unroll
+            for (int p = 0; p < PPB; ++p) sh[((ks - 1) * PPB + p) * JW + tj] = acc[p];
+        }
+        __syncthreads();
+        if (ks == 0) {
+            for (int s_ = 1; s_ < KS; ++s_)
+#pragma unroll
+                for (int p = 0; p < PPB; ++p) acc[p] += sh[((s_ - 1) * PPB + p) * JW + tj];
+        }
+    }
     // softmax over the HW logits of each position
     const int wave = t >> 6, lane = t & 63, nw = blockDim.x >> 6;
     float m[PPB];
 #pragma unroll
     for (int p = 0; p < PPB; ++p) {
-        float v = t < HW ? acc[p] : -3.0e38f;
+        float v = owner ? acc[p] : -3.0e38f;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
         if (lane == 0) red[wave * PPB + p] = v;
@@ -609,19 +628,19 @@ __global__ __launch_bounds__(256) void af_policy_head(const float* __restrict__ 
     float e[PPB];
 #pragma unroll
     for (int p = 0; p < PPB; ++p) {
-        e[p] = t < HW ? expf(acc[p] - m[p]) : 0.0f;
+        e[p] = owner ? expf(acc[p] - m[p]) : 0.0f;
         float v = e[p];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
         if (lane == 0) red[wave * PPB + p] = v;
     }
     __syncthreads();
-    if (t < HW) {
+    if (owner) {
 #pragma unroll
         for (int p = 0; p < PPB; ++p) {
-            float s = red[p];
-            for (int w_ = 1; w_ < nw; ++w_) s += red[w_ * PPB + p];
-            if (b0 + p < batch) policy[(size_t)(b0 + p) * HW + t] = e[p] / s;
+            float s_ = red[p];
+            for (int w_ = 1; w_ < nw; ++w_) s_ += red[w_ * PPB + p];
+            if (b0 + p < batch) policy[(size_t)(b0 + p) * HW + tj] = e[p] / s_;
         }
     }
 }
@@ -922,7 +941,7 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     }
     if (HW <= 128) {
         const size_t lds = ((size_t)16 * HW * 8 + 512 + 32) * 4;
-        hipLaunchKernelGGL((af_policy_head<8>), dim3((batch + 7) / 8), dim3(128), lds, st, o[4], n->pc_w, n->pc_b, n->pf_w,
+        hipLaunchKernelGGL((af_policy_head<8>), dim3((batch + 7) / 8), dim3(256), lds, st, o[4], n->pc_w, n->pc_b, n->pf_w,
                            n->pf_b, policy, batch, S, WP, PP);
     } else {
         const size_t lds = ((size_t)16 * HW * 4 + 512 + 16) * 4;
