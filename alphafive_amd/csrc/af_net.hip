@@ -668,6 +668,8 @@ struct af_net {
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> events;
     hipEvent_t ev_start = nullptr;
+    hipStream_t branch_stream = nullptr;
+    hipEvent_t ev_trunk = nullptr, ev_value = nullptr;
     float *vc_w, *vc_b, *v1_w, *v1_b, *v2_w, *v2_b, *pc_w, *pc_b, *pf_w, *pf_b;
     // activations [max_batch][C][PP]
     float *f0, *g[5], *o[5];
@@ -839,6 +841,11 @@ int af_net_finalize(af_net* n) {
         if (!rc) rc = net_alloc(n, &n->o[i], plane * kBlocks[i].cout, true);
     }
     if (rc) return rc;
+    if (!n->branch_stream) {
+        NET_HIP_OK(hipStreamCreateWithFlags(&n->branch_stream, hipStreamNonBlocking));
+        NET_HIP_OK(hipEventCreateWithFlags(&n->ev_trunk, hipEventDisableTiming));
+        NET_HIP_OK(hipEventCreateWithFlags(&n->ev_value, hipEventDisableTiming));
+    }
     n->ready = true;
     return AF_NET_OK;
 }
@@ -898,6 +905,7 @@ extern "C" {
 
 }  // extern "C"
 
+static int g_branch = 1;         // 1: value branch on a side stream
 static int g_substreams = 1;     // >1: split the batch into that many sub-batches, one HIP stream each
 static int g_subbatch = 0;       // 0: batch / g_substreams
 
@@ -914,8 +922,20 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     for (int i = 0; i < 5; ++i) { g[i] = n->g[i] + po * kBlocks[i].cout; o[i] = n->o[i] + po * kBlocks[i].cout; }
     hipLaunchKernelGGL(af_stem_conv, dim3(batch), dim3(256), 0, st, planes, n->stem_w, n->stem_b, f0, S, WP, PP);
     const float* block_in[5] = {f0, o[0], o[1], o[1], o[3]};
+    // the value branch (block3 + head) only depends on the trunk output o[1]: it runs on a side stream,
+    // concurrently with the policy branch (blocks 4,5 + head), filling the SIMDs the 32/64-wide layers leave idle
+    hipStream_t vs = st;
+    if (g_branch && n->branch_stream) {
+        vs = n->branch_stream;
+    }
     for (int i = 0; i < 5; ++i) {
         const Block& b = kBlocks[i];
+        hipStream_t st_main = st;
+        if (i == 2 && vs != st_main) {
+            NET_HIP_OK(hipEventRecord(n->ev_trunk, st_main));
+            NET_HIP_OK(hipStreamWaitEvent(vs, n->ev_trunk, 0));
+        }
+        hipStream_t st = (i == 2) ? vs : st_main;
         if (g_wino) {
             // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
             launch_wino(st, n, batch, block_in[i], g_wino == 2 ? n->wino1_ul[i] : n->wino1_u[i], b.cin, nullptr, nullptr, 0,
@@ -935,9 +955,11 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
             a.bias = n->sum_b[i]; a.out = o[i];
             launch_conv(st, a);
         }
-        if (i == 2)
+        if (i == 2) {
             hipLaunchKernelGGL(af_value_head, dim3(batch), dim3(256), 0, st, o[2], n->vc_w, n->vc_b, n->v1_w, n->v1_b,
                                n->v2_w, n->v2_b, value, S, WP, PP);
+            if (vs != st_main) NET_HIP_OK(hipEventRecord(n->ev_value, vs));
+        }
     }
     if (HW <= 128) {
         const size_t lds = ((size_t)16 * HW * 8 + 512 + 32) * 4;
@@ -948,6 +970,7 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
         hipLaunchKernelGGL((af_policy_head<4>), dim3((batch + 3) / 4), dim3(256), lds, st, o[4], n->pc_w, n->pc_b, n->pf_w,
                            n->pf_b, policy, batch, S, WP, PP);
     }
+    if (vs != st) NET_HIP_OK(hipStreamWaitEvent(st, n->ev_value, 0));
     NET_HIP_OK(hipGetLastError());
     return AF_NET_OK;
 }
@@ -991,6 +1014,7 @@ int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, 
 
 int af_net_tune(int32_t cout_pad, int32_t shape) {
     if (cout_pad == 0) { g_wino = shape; return AF_NET_OK; }     // 0: conv path (2 Winograd+LDS, 1 Winograd, 0 direct)
+    if (cout_pad == 4) { g_branch = shape; return AF_NET_OK; }                      // 4: value branch on a side stream (1/0)
     if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)
     if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
     if (cout_pad == 2) { g_subbatch = shape; return AF_NET_OK; }                     // 2: sub-batch size (0 = batch/streams)
