@@ -141,3 +141,126 @@ def resolve_checkpoint(path):
     if os.path.exists(path + ".index"):
         return path
     raise FileNotFoundError("Could not find old network weights")
+
+
+# ---------------------------------------------------------------------------------------------
+# writer — lets the untouched TF trainer / GUI (network.py:113-122) restore weights produced here
+# ---------------------------------------------------------------------------------------------
+_CRC_TABLE = None
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli), as used by TensorBundle entries and SSTable block trailers."""
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            tab.append(c)
+        _CRC_TABLE = np.array(tab, np.uint32)
+    crc ^= 0xFFFFFFFF
+    tab = _CRC_TABLE
+    for b in bytes(data):
+        crc = int(tab[(crc ^ b) & 0xFF]) ^ (crc >> 8)
+    return crc ^ 0xFFFFFFFF
+
+
+def masked_crc32c(data):
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _enc_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _field(num, wt, payload):
+    return _enc_varint((num << 3) | wt) + payload
+
+
+def _entry_proto(dtype_enum, shape, offset, size, crc):
+    dims = b"".join(_field(2, 2, _enc_varint(len(d)) + d) for d in (_field(1, 0, _enc_varint(int(s))) for s in shape))
+    msg = _field(1, 0, _enc_varint(dtype_enum)) + _field(2, 2, _enc_varint(len(dims)) + dims)
+    if offset:
+        msg += _field(4, 0, _enc_varint(offset))
+    msg += _field(5, 0, _enc_varint(size)) + _field(6, 5, struct.pack("<I", crc))
+    return msg
+
+
+def _build_block(entries, restart_interval=16):
+    body, restarts, prev = bytearray(), [], b""
+    for i, (key, val) in enumerate(entries):
+        shared = 0
+        if i % restart_interval == 0:
+            restarts.append(len(body))
+        else:
+            while shared < min(len(prev), len(key)) and prev[shared] == key[shared]:
+                shared += 1
+        body += _enc_varint(shared) + _enc_varint(len(key) - shared) + _enc_varint(len(val)) + key[shared:] + val
+        prev = key
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        body += struct.pack("<I", r)
+    body += struct.pack("<I", len(restarts))
+    return bytes(body)
+
+
+def _with_trailer(block):
+    return block + b"\x00" + struct.pack("<I", masked_crc32c(block + b"\x00"))
+
+
+def _short_successor(key):
+    """LevelDB BytewiseComparator::FindShortSuccessor — the index key TF's table builder emits."""
+    for i, b in enumerate(key):
+        if b != 0xFF:
+            return key[:i] + bytes([b + 1])
+    return key
+
+
+def save_bundle(prefix, variables):
+    """Write `<prefix>.index` and `<prefix>.data-00000-of-00001` (single shard, fp32/int tensors) in the
+    layout tf.train.Saver produces: tensors in name order, no padding, masked crc32c per tensor."""
+    inv = {np.dtype(v): k for k, v in _DTYPES.items()}
+    names = sorted(variables)
+    data = bytearray()
+    entries = [(b"", _field(1, 0, _enc_varint(1)) + _field(3, 2, _enc_varint(2) + _field(1, 0, _enc_varint(1))))]
+    for name in names:
+        arr = np.ascontiguousarray(variables[name])
+        arr = arr.astype(arr.dtype.newbyteorder("<"), copy=False)
+        raw = arr.tobytes()
+        entries.append((name.encode(), _entry_proto(inv[np.dtype(arr.dtype.name)], arr.shape, len(data), len(raw),
+                                                    masked_crc32c(raw))))
+        data += raw
+    block = _build_block(entries)
+    out = bytearray(_with_trailer(block))
+    meta_off = len(out)
+    meta = _build_block([])
+    out += _with_trailer(meta)
+    index_off = len(out)
+    handle = _enc_varint(0) + _enc_varint(len(block))
+    index = _build_block([(_short_successor(entries[-1][0]), handle)])
+    out += _with_trailer(index)
+    footer = _enc_varint(meta_off) + _enc_varint(len(meta)) + _enc_varint(index_off) + _enc_varint(len(index))
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC)
+    out += footer
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(out))
+
+
+def write_checkpoint_state(directory, name):
+    """The `checkpoint` text file tf.train.get_checkpoint_state reads (network.py:114)."""
+    with open(os.path.join(directory, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))
