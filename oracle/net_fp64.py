@@ -55,3 +55,30 @@ def forward(variables, inputs):
     logits = logits - logits.max(axis=1, keepdims=True)
     e = np.exp(logits)
     return e / e.sum(axis=1, keepdims=True), val                                # :88
+
+
+def loss_terms(variables, boards, distrib, winner, weights):
+    """fp64 restatement of the loss graph (network.py:40-50): total, cross_entropy, value_loss, entropy."""
+    v = variables
+    x = np.asarray(boards, np.float64)
+    B = x.shape[0]
+    f = _elu(_conv2d(x, v["bone/conv1/kernel"], v["bone/conv1/bias"]))
+    f = _residual(f, v, "bone/block1")
+    f = _residual(f, v, "bone/block2")
+    val = _residual(f, v, "value/block3")
+    val = _elu(_conv2d(val, v["value/conv/kernel"], v["value/conv/bias"])).reshape(B, -1)
+    val = _elu(val @ v["value/fc1/kernel"].astype(np.float64) + v["value/fc1/bias"])
+    val = np.tanh((val @ v["value/fc2/kernel"].astype(np.float64) + v["value/fc2/bias"]) / 2)[:, 0]
+    pol = _residual(f, v, "policy/block4")
+    pol = _residual(pol, v, "policy/block5")
+    pol = _elu(_conv2d(pol, v["policy/conv/kernel"], v["policy/conv/bias"]))
+    logits = pol.reshape(B, -1) @ v["policy/fc/kernel"].astype(np.float64) + v["policy/fc/bias"]
+    z = logits - logits.max(axis=1, keepdims=True)
+    logsm = z - np.log(np.exp(z).sum(axis=1, keepdims=True))
+    x_entropy = (np.asarray(distrib, np.float64) * logsm).sum(axis=1)                       # :41
+    w = np.asarray(weights, np.float64)
+    value_sq = (val - np.asarray(winner, np.float64)) ** 2                                  # :44
+    l2 = sum((np.asarray(a, np.float64) ** 2).sum() / 2 for n, a in v.items() if "bias" not in n and "bn" not in n)  # :47-48
+    total = -(x_entropy * w).mean() + 2.0 * (value_sq * w).mean() + 4e-5 * l2               # :50
+    entropy = -(np.exp(logsm) * logsm).sum(axis=1).mean()
+    return dict(total=total, cross_entropy=-x_entropy.mean(), value_loss=value_sq.mean(), entropy=entropy)
