@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_PKG, "_lib", "libaf_hip.so")
+_LIBPATH = os.environ.get("AF_HIP_LIB") or os.path.join(_PKG, "_lib", "libaf_hip.so")
 
 MODE_SELFPLAY, MODE_EXTERNAL = 0, 1
 STATUS_IDLE, STATUS_NEED_EVAL, STATUS_MOVE_DONE = 0, 1, 2
