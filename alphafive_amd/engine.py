@@ -251,6 +251,8 @@ class SelfPlayEngine:
         self.policy = torch.zeros((num_games, S * S), dtype=torch.float32, device=self.dev)
         self.value = torch.zeros((num_games,), dtype=torch.float32, device=self.dev)
         self.pv_device = pv_device
+        if hasattr(pv_device, "bind_outputs"):       # the HIP net writes into our tensors: no copy per tick
+            pv_device.bind_outputs(self.policy, self.value)
         self.ticks = 0
 
     def tick(self):

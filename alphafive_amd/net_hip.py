@@ -59,6 +59,12 @@ class HipNet(object):
         self.policy = torch.empty((max_batch, board_size * board_size), dtype=torch.float32, device=self.device)
         self.value = torch.empty((max_batch,), dtype=torch.float32, device=self.device)
 
+    def bind_outputs(self, policy, value):
+        """Write results straight into caller-owned device tensors (no copy on the tick path)."""
+        assert policy.is_contiguous() and value.is_contiguous() and policy.dtype == torch.float32
+        assert policy.shape[0] >= self.max_batch or policy.shape[0] == value.shape[0]
+        self.policy, self.value = policy, value
+
     def __call__(self, planes):
         B = planes.shape[0]
         assert B <= self.max_batch and planes.is_contiguous() and planes.dtype == torch.float32
@@ -83,7 +89,7 @@ def make_eval(resnet):
     if resnet.device.type != "cuda" or not (3 <= resnet.board_size <= 15):
         return None
     lib()
-    state = {"net": None}
+    state = {"net": None, "out": None}
 
     def pv(planes):
         B = planes.shape[0]
@@ -91,8 +97,16 @@ def make_eval(resnet):
             if state["net"] is not None:
                 state["net"].close()
             state["net"] = HipNet(resnet.variables, resnet.board_size, B, resnet.device)
+            if state["out"] is not None and state["out"][0].shape[0] >= B:
+                state["net"].bind_outputs(*state["out"])
         return state["net"](planes)
 
+    def bind_outputs(policy, value):
+        state["out"] = (policy, value)
+        if state["net"] is not None and policy.shape[0] >= state["net"].max_batch:
+            state["net"].bind_outputs(policy, value)
+
+    pv.bind_outputs = bind_outputs
     return pv
 
 
