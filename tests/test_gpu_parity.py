@@ -159,3 +159,36 @@ def test_engine_fails_loudly_on_full_store():
             e.status()
             e.set_root(0, eng.state_to_key("g/g/g/g/g/g/", 6))
     e.close()
+
+
+def test_batched_arena_matches_per_game_oracle_players():
+    """alphafive_amd.arena.play_matches (choose_best_player.py:38-60, many games at once) vs the same
+    protocol played game by game with two oracle players on their own trees."""
+    import torch
+    from alphafive_amd import arena, utils
+    S, goal, G = 6, 4, 10
+    cfg = make_cfg(board_size=S, goal=goal, simulation_per_step=40, upper_simulation_per_step=60)
+    nets = [(101, 16384), (202, 4096)]
+    pvs = [(lambda x, sp=sp: pseudonet.pseudonet_torch(x, sp[0], sp[1])) for sp in nets]
+    out = arena.play_matches(cfg, pvs[0], pvs[1], G, seed0=5, seed1=6)
+    wins, draws = [0, 0], 0
+    for i in range(G):
+        players = [oracle.OraclePlayer(cfg, training=False, rng_mode=oracle.RNG_PHILOX, seed=s, game_id=i,
+                                       pseudo_salt=sp[0], pseudo_peak=sp[1]) for s, sp in zip((5, 6), nets)]
+        for pl in players:
+            pl.reset()
+        board = np.zeros((S, S), np.int8)
+        state, action, cur, over, seq = utils.board_to_state(board), None, i % 2, False, []
+        while not over:
+            _, action, _ = players[cur].get_action(state, action, random_a=True)
+            seq.append(action[0] * S + action[1])
+            board = utils.step(utils.state_to_board(state, S), action)
+            state = utils.board_to_state(board)
+            over, v = utils.is_game_over(board, goal)
+            cur = (cur + 1) % 2
+        assert seq == out["moves"][i], f"game {i}"
+        if v == 0.0:
+            draws += 1
+        else:
+            wins[(cur + 1) % 2] += 1
+    assert wins == out["wins"] and draws == out["draws"]
