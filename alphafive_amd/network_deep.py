@@ -1,0 +1,51 @@
+"""BASELINE configs[4]: a deeper policy/value net — N residual blocks of the reference's block type
+(network.py:52-56: 1x1 projection || 3x3+ELU -> 3x3, add, ELU) at constant width, the reference's two heads,
+evaluated in bf16 on PyTorch-ROCm ops.  Performance-only configuration (no checkpoint exists for
+it, random init, no bit parity); it plugs into SelfPlayEngine through the same
+planes[G,3,S,S] -> (prob[G,C], value[G]) evaluator seam as the fp32 net.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+class DeepResNet(object):
+    def __init__(self, board_size, blocks=8, width=128, device="cuda", dtype=torch.bfloat16, seed=0):
+        self.board_size, self.blocks, self.width = board_size, blocks, width
+        self.device, self.dtype = torch.device(device), dtype
+        g = torch.Generator().manual_seed(seed)
+        C = board_size * board_size
+
+        def glorot(*shape):                      # OIHW / [in,out], tf.layers default initialiser
+            rf = int(np.prod(shape[2:])) if len(shape) == 4 else 1
+            fan_in, fan_out = (shape[1] * rf, shape[0] * rf) if len(shape) == 4 else (shape[0], shape[1])
+            lim = float(np.sqrt(6.0 / (fan_in + fan_out)))
+            return ((torch.rand(shape, generator=g) * 2 - 1) * lim).to(self.device, dtype)
+
+        z = lambda n: torch.zeros(n, device=self.device, dtype=dtype)  # noqa: E731
+        self.stem = (glorot(width, 3, 5, 5), z(width))
+        self.tower = [dict(res=(glorot(width, width, 1, 1), z(width)), c1=(glorot(width, width, 3, 3), z(width)),
+                           c2=(glorot(width, width, 3, 3), z(width))) for _ in range(blocks)]
+        self.vconv, self.pconv = (glorot(4, width, 1, 1), z(4)), (glorot(16, width, 1, 1), z(16))
+        self.vfc1, self.vfc2 = (glorot(4 * C, 64), z(64)), (glorot(64, 1), z(1))
+        self.pfc = (glorot(16 * C, C), z(C))
+
+    def flops_per_position(self):
+        HW, w = self.board_size ** 2, self.width
+        mac = 75 * w * HW + self.blocks * (w * w + 18 * w * w) * HW + (4 + 16) * w * HW + 4 * HW * 64 + 64 + 16 * HW * HW
+        return 2 * mac
+
+    @torch.no_grad()
+    def eval_device(self, x):
+        B = x.shape[0]
+        h = F.elu(F.conv2d(x.to(self.dtype), self.stem[0], self.stem[1], padding=2))
+        for blk in self.tower:
+            r = F.conv2d(h, *blk["res"])
+            g = F.elu(F.conv2d(h, *blk["c1"], padding=1))
+            h = F.elu(r + F.conv2d(g, *blk["c2"], padding=1))
+        v = F.elu(F.conv2d(h, *self.vconv)).reshape(B, -1)
+        v = F.elu(v @ self.vfc1[0] + self.vfc1[1])
+        v = torch.tanh((v @ self.vfc2[0] + self.vfc2[1]).float() / 2).squeeze(1)
+        p = F.elu(F.conv2d(h, *self.pconv)).reshape(B, -1)
+        p = torch.softmax((p @ self.pfc[0] + self.pfc[1]).float(), dim=1)
+        return p, v

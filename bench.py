@@ -88,7 +88,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--net", default="auto", choices=["auto", "torch", "hip"])
+    ap.add_argument("--net", default="auto", choices=["auto", "torch", "hip", "deep-bf16"],
+                    help="deep-bf16 = BASELINE configs[4]: 8-block width-128 net in bf16 (use with --games 8192)")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +129,13 @@ def main():
         net.load_npz(weights)                     # other sizes: random init of the same architecture (no checkpoint exists)
     if world > 1:
         afdist.broadcast_weights(net, src=0)      # one 3 MB broadcast, as a weight update would do
-    pv = net.select_backend(args.net)
+    deep = None
+    if args.net == "deep-bf16":
+        from alphafive_amd.network_deep import DeepResNet
+        deep = DeepResNet(cfg.board_size, blocks=8, width=128, device=dev)
+        pv = deep.eval_device
+    else:
+        pv = net.select_backend(args.net)
     sp = SelfPlayEngine(cfg, G, pv, device=local, seed=args.seed, first_game_id=rank * G)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
@@ -203,13 +210,19 @@ def main():
         tick_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_tick]))
         net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net]))
         flop_pos = FLOP_PER_POSITION if cfg.board_size == 11 else net.flops_per_position()
+        peak, dtype_name = PEAK_FP32_MFMA_TFLOPS, "f32"
+        if deep is not None:
+            flop_pos, peak, dtype_name = deep.flops_per_position(), 2500.0, "bf16"   # dense bf16 MFMA peak
         net_tflops = G * flop_pos / (net_ms * 1e-3) / 1e12
         tree_gbs = tree_bytes(d, C) / n_ticks / (tick_ms * 1e-3) / 1e9
         roof = net.roofline_info(pv)
+        if deep is not None:
+            roof = {"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
+                    "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"}
         out = {
             "metric": "self-play moves/sec (%dx%d, %d sims/move)" % (cfg.board_size, cfg.board_size, args.sims), "value": total_plies / t, "unit": "moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[1]: {G} concurrent 11x11 games per GPU, {args.sims} sims/move "
                                     f"(cap {args.upper}), training-mode MCTS, alphaFive-6960 net fp32, batched leaf eval")
                        if cfg.board_size == 11 else
@@ -222,7 +235,7 @@ def main():
                        "terminal_frac": d["terminals"] / max(1, d["sims"]),
                        "episodes_gathered": gathered["episodes"]},
             "roofline": {"kernel": roof["kernel"], "bound": "mfma", "achieved": net_tflops,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": net_tflops / PEAK_FP32_MFMA_TFLOPS,
+                         "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "traffic": None, "ms_per_launch": net_ms,
                          "flop_per_launch": G * flop_pos},
             "tree_roofline": {"kernel": "af_tick_kernel<%d>" % (2 if C <= 128 else 4), "bound": "hbm", "achieved": tree_gbs,
