@@ -1,23 +1,19 @@
 // af_net.hip — hand-written gfx950 forward pass of the alphaFive policy/value net
-// (genData/network.py:52-97,163-165) in fp32 on the matrix cores.
+// (genData/network.py:52-97,163-165), fp32 on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+// products, fp32 accumulate).  C ABI: include/af_net.h.
 //
-// Every 3x3 convolution (97 % of the FLOPs) and the 1x1 projection of each residual block run in
-// ONE implicit-GEMM kernel, af_conv_mfma<NT,MT>:   D[cout][pixel] = sum_k W[k][cout] * X[k][pixel]
-//   * v_mfma_f32_32x32x2_f32: A operand = 32 couts x 2 k (weights), B operand = 2 k x 32 pixels
-//     (activations), 16 accumulator registers per 32x32 tile; exact fp32 (an fmaf chain in k order).
-//   * k runs over (cin pair, tap): a tap is a constant address shift in the zero-padded plane
-//     layout [b][c][(S+2)*(S+2) (+pad)], so the B fragment is one global_load_dword per lane with
-//     32 consecutive pixels per k — no im2col, no LDS staging (fp32 MFMA needs only 2 operand
-//     dwords per 64-cycle instruction; operands come straight from L1/L2 with register reuse:
-//     each weight fragment feeds MT pixel tiles, each activation fragment feeds NT cout tiles).
-//   * weights are pre-packed k-pair-major ([cin/2][tap][2][cout]) so every wave streams them
-//     linearly; the block's 1x1 projection is appended to the k loop as a second segment;
-//     bias, residual add and ELU are fused in the epilogue, which writes straight into the next
-//     layer's padded layout (rows of the D tile are couts, so stores are pixel-contiguous).
-//   * pixel tiles run over the flattened batch (row = b*S*S + pixel): no per-position padding
-//     waste; one wave owns MT pixel tiles x all couts (NT*MT*16 <= 128 accumulator VGPRs).
-// The 5x5 stem (0.25 % of FLOPs) and the two heads (1x1 conv + dense + tanh / softmax, 0.6 %)
-// are small VALU kernels.
+// Activations live in zero-padded planes [batch][channel][WP*WP (+pad)], WP = 2*ceil(S/2)+2, so a
+// convolution tap is a constant address shift and no kernel needs bounds checks; every layer writes
+// straight into the next layer's padded layout.  Kernels:
+//   af_conv_wino<LDSU>   (default path, 97 % of the algorithmic FLOPs) Winograd F(2x2,3x3) for every 3x3
+//                        layer with the block's 1x1 projection folded into the Winograd domain; 16
+//                        accumulators in AGPRs, on-the-fly input transform, fused output transform +
+//                        bias + residual + ELU.  3.45 of the 3.86 ms per 4096 leaves.
+//   af_conv_mfma<NT,MT>  direct implicit GEMM (D[cout][pixel] = sum_k W[k][cout] X[k][pixel], k = (cin pair,
+//                        tap)), operands straight from L1/L2 into registers; the pre-Winograd path
+//                        (af_net_tune(0, 0)), kept as the exact-fp32-order reference and for A/B runs.
+//   af_stem_conv, af_value_head, af_policy_head<PPB>   5x5 stem and the two heads (VALU, 0.36 ms together).
+// Measured ladder and the experiments that did not pay are in DESIGN.md §3.2 and profiles/.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -852,8 +848,6 @@ int af_net_finalize(af_net* n) {
 
 }  // extern "C"
 
-// tile-shape selection per cout width (tuning knob, see af_net_tune): index = cout_pad/32 - 1 (.. 3 for 128)
-static int g_shape[4] = {0, 0, 0, 0};
 static int g_abl = 0;    // profiling: ablation variant of af_conv_wino<false>
 static int g_wino = 1;   // 1: af_conv_wino<false> (default); 2: af_conv_wino<true> (U through LDS: measured 6 % slower); 0: direct af_conv_mfma
 
@@ -880,24 +874,11 @@ static void launch_shape(hipStream_t st, const ConvArgs& a) {
 
 static void launch_conv(hipStream_t st, const ConvArgs& a) {
     if (a.cout_pad == 128) {
-        switch (g_shape[3]) {
-            case 1: launch_shape<4, 1, 2>(st, a); break;
-            case 2: launch_shape<4, 1, 3>(st, a); break;
-            default: launch_shape<4, 2, 1>(st, a); break;
-        }
+        launch_shape<4, 2, 1>(st, a);      // r1: <4,1> at 2-3 waves/SIMD measured 5 % slower
     } else if (a.cout_pad == 64) {
-        switch (g_shape[1]) {
-            case 1: launch_shape<2, 2, 2>(st, a); break;
-            case 2: launch_shape<2, 2, 3>(st, a); break;
-            default: launch_shape<2, 4, 1>(st, a); break;
-        }
+        launch_shape<2, 4, 1>(st, a);
     } else {
-        switch (g_shape[0]) {
-            case 1: launch_shape<1, 4, 2>(st, a); break;
-            case 2: launch_shape<1, 8, 1>(st, a); break;
-            case 3: launch_shape<1, 2, 4>(st, a); break;
-            default: launch_shape<1, 4, 1>(st, a); break;
-        }
+        launch_shape<1, 4, 1>(st, a);
     }
 }
 
@@ -1018,9 +999,7 @@ int af_net_tune(int32_t cout_pad, int32_t shape) {
     if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)
     if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
     if (cout_pad == 2) { g_subbatch = shape; return AF_NET_OK; }                     // 2: sub-batch size (0 = batch/streams)
-    if (cout_pad != 32 && cout_pad != 64 && cout_pad != 128) return AF_NET_ERR_ARG;
-    g_shape[cout_pad / 32 - 1] = shape;
-    return AF_NET_OK;
+    return AF_NET_ERR_ARG;
 }
 
 int64_t af_net_flops_per_position(const af_net* n) {

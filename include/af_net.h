@@ -42,9 +42,12 @@ int af_net_finalize(af_net* n);
  * Asynchronous on `stream` (hipStream_t; NULL = default stream). */
 int af_net_forward(af_net* n, void* stream, const float* planes_dev, int32_t batch, float* policy_dev, float* value_dev);
 
-/* Tuning knob: choose the MFMA tile shape used for layers of width cout_pad (32/64/128);
- * shape 0 = default.  Process-global; for benchmarking only. */
-int af_net_tune(int32_t cout_pad, int32_t shape);
+/* Benchmark / A-B knobs (process-global):
+ *   key 0: conv path — 1 Winograd (default), 2 Winograd with U shared through LDS, 0 direct implicit GEMM
+ *   key 1: number of sub-batch side streams (default 1)      key 2: sub-batch size (0 = batch / streams)
+ *   key 3: ablation variant of the Winograd kernel (profiling only; results are wrong by design)
+ *   key 4: value branch on a side stream (default 1) */
+int af_net_tune(int32_t key, int32_t value);
 
 /* FLOPs (2*MAC) of one position's forward pass, as executed (direct convolution). */
 int64_t af_net_flops_per_position(const af_net* n);

@@ -79,3 +79,24 @@ def test_flop_count_matches_survey():
     h = net_hip.HipNet(net.variables, 11, 4, net.device)
     assert h.flops_per_position == 118_727_264         # 59,363,632 MAC
     h.close()
+
+
+def test_alternate_conv_paths_agree_with_fp64():
+    """The direct implicit-GEMM path (af_net_tune(0,0)) and the LDS-shared-U Winograd path (0,2) stay correct."""
+    import torch
+    from alphafive_amd import net_hip
+    from alphafive_amd.network import ResNet
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    pv = net.select_backend("hip")
+    x = _positions(11, 70, seed=4)
+    xt = torch.from_numpy(x).cuda()
+    p64, v64 = net_fp64.forward(net.variables, x[:32])
+    try:
+        for mode in (0, 2, 1):
+            net_hip.tune(0, mode)
+            p, v = pv(xt)
+            assert np.abs(v[:32].cpu().numpy() - v64).max() < 1e-5, mode
+            assert np.abs(p[:32].cpu().numpy() - p64).max() < 1e-5, mode
+    finally:
+        net_hip.tune(0, 1)
