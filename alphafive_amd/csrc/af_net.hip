@@ -207,7 +207,7 @@ struct WinoArgs {
 
 // LDSU = true: the U stream of the 3x3 segment is shared by the workgroup through LDS (A.u in the
 // slice layout of pack_wino_lds); false: every wave loads its own U fragments (A.u from pack_wino).
-template <bool LDSU, int ABL = 0>   // ABL (profiling only): 1 = no operand loads in the 3x3 loop, 2 = no input transform
+template <bool LDSU, int ABL = 0>   // ABL (profiling only): 1 no operand loads in the 3x3 loop, 2 no input transform, 3 no k loops, 4 no epilogue
 __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
     __shared__ float4 su[LDSU ? 3 * 4 * 256 : 1];       // 3 buffers x 4 pair slices x 4 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -431,6 +431,13 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
             phase(q + 5, d1, u1, d2, u2);
             phase(q + 6, d2, u2, d3, u3);
         }
+    }
+    if constexpr (ABL == 4) {          // profiling: no epilogue (keep M alive so the loops are not dead code)
+        float sink = 0.0f;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) sink += M[x][0];
+        if (sink == 12345.678f) A.out[0] = sink;
+        return;
     }
     // ---- output transform Y = A^T M A, bias, ELU, store the 2x2 tile ----
     // (bias values were requested before the k loops; each tile row goes out as one 8-byte store, so the
@@ -860,6 +867,7 @@ static void launch_wino(hipStream_t st, const af_net* n, int batch, const float*
     const int ntb = (a.ntiles + 31) / 32;
     if (g_wino == 2) hipLaunchKernelGGL((af_conv_wino<true, 0>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
     else if (g_abl == 1) hipLaunchKernelGGL((af_conv_wino<false, 1>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 4) hipLaunchKernelGGL((af_conv_wino<false, 4>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
     else if (g_abl == 3) hipLaunchKernelGGL((af_conv_wino<false, 3>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
     else if (g_abl == 2) hipLaunchKernelGGL((af_conv_wino<false, 2>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((af_conv_wino<false, 0>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
