@@ -298,10 +298,47 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) u[r] = *reinterpret_cast<const float4*>(up + (size_t)r * 16 + (size_t)woff);
             };
-            auto phase = [&](int c_load, f4u (&dl)[4], float4 (&ul)[4], f4u (&dc)[4], float4 (&uc)[4]) {
-                load_d(c_load, dl);
-                load_u(c_load, ul);
-                compute_pair(dc, uc);
+            // the input transform runs ONE PHASE AHEAD of the MFMAs that consume it (v of pair c+1 is computed
+            // while pair c multiplies), so no MFMA waits on a VALU result issued just before it
+            auto transform = [&](f4u (&d)[4], float (&v)[16]) {
+                float t[16];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    t[0 + s_] = d[0][s_] - d[2][s_];
+                    t[4 + s_] = d[1][s_] + d[2][s_];
+                    t[8 + s_] = d[2][s_] - d[1][s_];
+                    t[12 + s_] = d[1][s_] - d[3][s_];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
+                    v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+                    v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+                    v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+                }
+            };
+            auto mfma16 = [&](float4 (&u)[4], float (&v)[16]) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    M[4 * x + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].x, v[4 * x + 0], M[4 * x + 0], 0, 0, 0);
+                    M[4 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].y, v[4 * x + 1], M[4 * x + 1], 0, 0, 0);
+                    M[4 * x + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].z, v[4 * x + 2], M[4 * x + 2], 0, 0, 0);
+                    M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, v[4 * x + 3], M[4 * x + 3], 0, 0, 0);
+                }
+            };
+            float vA[16], vB[16];
+            auto phase = [&](int c_load, f4u (&dl)[4], float4 (&ul)[4], f4u (&dn)[4], float (&vn)[16], float4 (&uc)[4],
+                             float (&vc)[16]) {
+                if constexpr (ABL == 0) {
+                    load_d(c_load + 1, dl);    // a patch slot is free one phase earlier than a U slot: 4-phase lead
+                    load_u(c_load, ul);
+                    transform(dn, vn);
+                    mfma16(uc, vc);
+                } else {
+                    load_d(c_load, dl);
+                    load_u(c_load, ul);
+                    compute_pair(dn, uc);      // ablation variants keep the in-phase form (dn == this pair's d there)
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
@@ -316,11 +353,23 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
             load_d(1, d1); load_u(1, u1);
             load_d(2, d2); load_u(2, u2);
             __builtin_amdgcn_sched_barrier(0);
-            for (int c = 0; c < npairs; c += 4) {
-                phase(c + 3, d3, u3, d0, u0);
-                phase(c + 4, d0, u0, d1, u1);
-                phase(c + 5, d1, u1, d2, u2);
-                phase(c + 6, d2, u2, d3, u3);
+            if constexpr (ABL == 0) {
+                load_d(3, d3);
+                transform(d0, vA);
+                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < npairs; c += 4) {
+                    phase(c + 3, d0, u3, d1, vB, u0, vA);     // multiply pair c, transform pair c+1, load U c+3 / patch c+4
+                    phase(c + 4, d1, u0, d2, vA, u1, vB);
+                    phase(c + 5, d2, u1, d3, vB, u2, vA);
+                    phase(c + 6, d3, u2, d0, vA, u3, vB);
+                }
+            } else {
+                for (int c = 0; c < npairs; c += 4) {
+                    phase(c + 3, d3, u3, d0, vA, u0, vA);
+                    phase(c + 4, d0, u0, d1, vA, u1, vA);
+                    phase(c + 5, d1, u1, d2, vA, u2, vA);
+                    phase(c + 6, d2, u2, d3, vA, u3, vA);
+                }
             }
         } else {
             // U through LDS: a (pair, ct) slice is 4 KB laid out [x][lane][4] (pack_wino_lds), i.e. exactly
