@@ -216,6 +216,18 @@ def main():
         net_tflops = G * flop_pos / (net_ms * 1e-3) / 1e12
         tree_gbs = tree_bytes(d, C) / n_ticks / (tick_ms * 1e-3) / 1e9
         roof = net.roofline_info(pv)
+        # HBM traffic per launch: NOT measured live (PMC collection needs its own rocprofv3 passes); taken from the
+        # committed counter profile when this run is the profiled workload, else null
+        traffic_net = traffic_tick = None
+        traffic_src = None
+        tp = os.path.join(REPO, "profiles", "r1_08_pmc_hbm_traffic.json")
+        if os.path.exists(tp) and deep is None and roof["backend"].startswith("hip"):
+            with open(tp) as f:
+                prof = json.load(f)
+            if prof["workload"] == {"games": G, "board_size": cfg.board_size}:
+                traffic_net = prof["net_forward_bytes_per_launch"]["corrected"]
+                traffic_tick = prof["tick_kernel_bytes_per_launch"]["corrected"]
+                traffic_src = "profiles/r1_08_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         if deep is not None:
             roof = {"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
                     "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"}
@@ -236,10 +248,10 @@ def main():
                        "episodes_gathered": gathered["episodes"]},
             "roofline": {"kernel": roof["kernel"], "bound": "mfma", "achieved": net_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
-                         "traffic": None, "ms_per_launch": net_ms,
+                         "traffic": traffic_net, "traffic_source": traffic_src, "ms_per_launch": net_ms,
                          "flop_per_launch": G * flop_pos},
             "tree_roofline": {"kernel": "af_tick_kernel<%d>" % (2 if C <= 128 else 4), "bound": "hbm", "achieved": tree_gbs,
-                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": None,
+                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": traffic_tick,
                               "ms_per_launch": tick_ms, "bytes_per_launch": tree_bytes(d, C) / n_ticks},
             "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms},
         }
