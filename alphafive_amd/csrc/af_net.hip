@@ -213,8 +213,12 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, kh = lane >> 5;
     const int nct = A.cout >> 5;
-    const int ct = blockIdx.x % nct;
-    const int tb = (blockIdx.x / nct) * 4 + wave;
+    // XCD-aware block -> task map: workgroup b is observed to run on XCD b % 8 and each XCD has its own L2.
+    // The nct workgroups that read the SAME activations (same tile-block group, different cout tile) get the
+    // block ids g8, g8+8, g8+16, ... so they share one XCD's L2 instead of fetching the planes nct times.
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int ct = rest % nct;
+    const int tb = ((rest / nct) * 8 + xcd) * 4 + wave;
     const bool wave_live = tb * 32 < A.ntiles;           // (a dead wave still helps stage U and hits the barriers)
     if (!LDSU && !wave_live) return;
     const int q = tb * 32 + col;
@@ -914,12 +918,13 @@ static void launch_wino(hipStream_t st, const af_net* n, int batch, const float*
     a.cin = cin; a.cin2 = cin2; a.cout = cout; a.T = n->T; a.S = n->S; a.WP = n->WP; a.PP = n->PP;
     a.ntiles = batch * n->T * n->T;
     const int ntb = (a.ntiles + 31) / 32;
-    if (g_wino == 2) hipLaunchKernelGGL((af_conv_wino<true, 0>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 1) hipLaunchKernelGGL((af_conv_wino<false, 1>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 4) hipLaunchKernelGGL((af_conv_wino<false, 4>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 3) hipLaunchKernelGGL((af_conv_wino<false, 3>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 2) hipLaunchKernelGGL((af_conv_wino<false, 2>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((af_conv_wino<false, 0>), dim3(((ntb + 3) / 4) * (cout / 32)), dim3(256), 0, st, a);
+    const int ngrp8 = (((ntb + 3) / 4) + 7) / 8 * 8;      // tile-block groups, padded to the 8-XCD interleave
+    if (g_wino == 2) hipLaunchKernelGGL((af_conv_wino<true, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 1) hipLaunchKernelGGL((af_conv_wino<false, 1>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 4) hipLaunchKernelGGL((af_conv_wino<false, 4>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 3) hipLaunchKernelGGL((af_conv_wino<false, 3>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 2) hipLaunchKernelGGL((af_conv_wino<false, 2>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((af_conv_wino<false, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
 }
 
 template <int NT, int MT, int MINW>
