@@ -151,8 +151,8 @@ def gen_rules(path):
     print("rules:", len(cases), "cases")
 
 
-def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, random_a=False, reset_every=None):
-    cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper)
+def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, random_a=False, reset_every=None, **cfg_kw):
+    cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper, **cfg_kw)
     np.random.seed(seed)
     random.seed(seed)
     pl = Player(cfg, training=training, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak))
@@ -192,8 +192,8 @@ def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, 
     print(os.path.basename(path), "plies", ply, "nodes", len(pl.tree), "over", over)
 
 
-def gen_run(path, S, goal, sims, upper, seed, salt, peak, episodes):
-    cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper)
+def gen_run(path, S, goal, sims, upper, seed, salt, peak, episodes, **cfg_kw):
+    cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper, **cfg_kw)
     np.random.seed(seed)
     random.seed(seed)
     pl = Player(cfg, training=True, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak))
@@ -274,7 +274,21 @@ def gen_randomstack(path):
     print("randomstack:", sum(accepted), "accepted of", len(episodes), "buffer", len(st.data))
 
 
+def gen_edge_cases(G):
+    """Edge cases of the path: drawn games on a full board (3x3, goal 3: value 0.0 stays a python float),
+    the tau <= 0.01 branch of calc_policy (player.py:112-115), a simulation cap that leaves few or no
+    simulations (upper - sum_n <= 0, player.py:143), other c_puct / alpha / decay values."""
+    gen_run(G("run_s3_draws.npz"), 3, 3, 30, 40, 4, 900, 0, 6)       # seed 4: two of the six games are draws
+    gen_run(G("run_s4_lowtau.npz"), 4, 3, 24, 30, 22, 901, 4096, 3, init_temp=0.0105)
+    gen_mcts(G("mcts_s5_cap.npz"), 5, 4, 30, 31, True, 23, 902, 16384, 40)
+    gen_mcts(G("mcts_s6_params.npz"), 6, 4, 50, 70, True, 24, 903, 8192, 40, c_puct=1.5, dirichlet_alpha=0.15,
+             tau_decay_rate=0.8, init_temp=2.0)
+
+
 def main():
+    if "--only-edges" in sys.argv:
+        gen_edge_cases(lambda name: os.path.join(HERE, name))
+        return
     if "--only-randomstack" in sys.argv:
         gen_randomstack(os.path.join(HERE, "randomstack.npz"))
         return
@@ -296,6 +310,7 @@ def main():
     # whole episodes through Player.run (tree reset, value signs, weights, result code)
     gen_run(G("run_s6.npz"), 6, 4, 60, 80, 11, 4242, 16384, 3)
     gen_run(G("run_s7.npz"), 7, 4, 40, 60, 12, 4243, 4096, 2)
+    gen_edge_cases(G)
 
 
 if __name__ == "__main__":

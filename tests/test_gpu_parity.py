@@ -192,3 +192,47 @@ def test_batched_arena_matches_per_game_oracle_players():
         else:
             wins[(cur + 1) % 2] += 1
     assert wins == out["wins"] and draws == out["draws"]
+
+
+@pytest.mark.parametrize("kw,G", [
+    (dict(board_size=3, goal=3, simulation_per_step=30, upper_simulation_per_step=40), 32),       # full-board draws
+    (dict(board_size=4, goal=3, simulation_per_step=24, upper_simulation_per_step=30, init_temp=0.0105), 24),  # tau <= 0.01
+    (dict(board_size=5, goal=4, simulation_per_step=30, upper_simulation_per_step=31), 24),       # cap: few/no sims left
+    (dict(board_size=6, goal=4, simulation_per_step=50, upper_simulation_per_step=70, c_puct=1.5,
+          dirichlet_alpha=0.15, tau_decay_rate=0.8, init_temp=2.0), 24),
+    (dict(board_size=9, goal=5, simulation_per_step=40, upper_simulation_per_step=60), 16),
+])
+def test_selfplay_edge_cases_match_oracle(kw, G):
+    """Same edge cases as the tier-A goldens (run_s3_draws, run_s4_lowtau, mcts_s5_cap, mcts_s6_params):
+    drawn games, the low-temperature branch of calc_policy, a nearly exhausted simulation cap, other
+    hyper-parameters — HIP engine vs oracle, bit for bit."""
+    from alphafive_amd.engine import SelfPlayEngine, assemble_episode
+    cfg = make_cfg(**kw)
+    S = cfg.board_size
+    salt, peak, seed = 900, 4096 if S > 3 else 0, 77
+    sp = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, salt, peak), device=0, seed=seed)
+    got = {}
+    for _ in range(400):
+        sp.run_ticks(50)
+        sp.check()
+        for raw in sp.pop_raw(cap=128):
+            got.setdefault(raw["game"], []).append(raw)
+        if all(len(got.get(g, [])) >= 2 for g in range(G)):
+            break
+    assert all(len(got.get(g, [])) >= 2 for g in range(G))
+    draws = 0
+    for g in range(0, G, 3):
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=seed, game_id=g,
+                                  pseudo_salt=salt, pseudo_peak=peak)
+        for raw in got[g][:3]:
+            orec, extra = orc.run()
+            assert raw["T"] == len(orec) and (raw["actions"] == extra["actions"]).all(), f"game {g} seq {raw['seq']}"
+            assert (raw["visits"] == extra["visits"]).all() and raw["final_value"] == extra["final_value"]
+            rec, result = assemble_episode(raw, S, cfg.gamma)
+            for (s, p, la, v, w), (os_, op, ola, ov, ow) in zip(rec, orec):
+                assert s == os_ and la == ola and v == ov and w == ow
+                assert (p.view(np.uint32) == op.view(np.uint32)).all()
+            draws += result == 0
+    if S == 3:
+        assert draws > 0, "the 3x3 case is there to exercise drawn games"
+    sp.close()
