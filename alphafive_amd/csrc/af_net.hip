@@ -828,6 +828,8 @@ int af_net_create(int32_t S, int32_t max_batch, int32_t device, af_net** out) {
     n->WP = 2 * n->T + 2;                    // plane padded so every tile's 4x4 patch is in bounds
     n->PP = (n->WP * n->WP + 15) / 16 * 16;
     n->max_batch = max_batch; n->device = device;
+    // the conv kernels address activations with 32-bit byte offsets: the widest buffer must stay below 4 GiB
+    if ((uint64_t)max_batch * 128u * (uint64_t)n->PP * 4u >= (1ull << 32)) { delete n; return AF_NET_ERR_ARG; }
     const size_t HW = n->HW;
     n->expect["bone/conv1/kernel"] = 75 * 32; n->expect["bone/conv1/bias"] = 32;
     for (const Block& b : kBlocks) {
@@ -849,6 +851,12 @@ void af_net_destroy(af_net* n) {
     if (!n) return;
     (void)hipSetDevice(n->device);
     for (void* p : n->allocs) (void)hipFree(p);
+    for (hipStream_t s_ : n->streams) (void)hipStreamDestroy(s_);
+    for (hipEvent_t e_ : n->events) (void)hipEventDestroy(e_);
+    if (n->branch_stream) (void)hipStreamDestroy(n->branch_stream);
+    if (n->ev_start) (void)hipEventDestroy(n->ev_start);
+    if (n->ev_trunk) (void)hipEventDestroy(n->ev_trunk);
+    if (n->ev_value) (void)hipEventDestroy(n->ev_value);
     delete n;
 }
 
