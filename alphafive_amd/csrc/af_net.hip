@@ -701,6 +701,132 @@ __global__ __launch_bounds__(256) void af_policy_head(const float* __restrict__ 
     }
 }
 
+// policy head on the matrix cores (boards up to 11x11), 16 positions per workgroup = one workgroup per CU
+// at 4096 leaves.  All three phases are matrix shaped, v_mfma_f32_16x16x4_f32 throughout:
+//   phase 1  1x1 conv 32->16 + ELU: D[co][item] = sum_ci wc[ci][co] x[ci][item] over tiles of 16 items
+//            (item = position*HW + pixel); A = the lane's 8 weights (registers), B = one dword per k-step
+//            straight from the padded planes, two tiles in flight; result -> X[pos][co*HW + pix] in LDS
+//            (the NCHW flatten order of network.py:83-84; row stride = 2 mod 32: conflict-free B reads later)
+//   phase 2  logits^T[j][pos] = sum_k Wfc[k][j] X[pos][k]: A = 16 logits x 4 k from global (64-byte runs,
+//            requested 16 k-steps = 1024 MFMA cycles ahead), B = 4 k x 16 positions from LDS; each wave owns
+//            two 16-logit tiles
+//   phase 3  logits -> LDS, softmax by 16-lane groups, store
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void af_policy_head_mfma(const float* __restrict__ in /*[b][32][PP]*/, const float* __restrict__ wc /*[32][16]*/,
+                                                           const float* __restrict__ bc, const float* __restrict__ wf /*[16HW][HW]*/,
+                                                           const float* __restrict__ bf, float* __restrict__ policy, int batch, int S, int WP, int PP) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = S * S, K = 16 * HW, t = threadIdx.x, b0 = blockIdx.x * 16;
+    const int KS = K + ((2 - K % 32) + 32) % 32;
+    float* X = smem;                                       // [16][KS]
+    const int lane = t & 63, wave = t >> 6, i16 = lane & 15, kq = lane >> 4;
+    {   // ---- phase 1 ----
+        float aw[8];                                       // A fragments: wc[ci = 4s+kq][co = i16]
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) aw[s_] = wc[(4 * s_ + kq) * 16 + i16];
+        float bias4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[r] = bc[kq * 4 + r];
+        const int nitems = 16 * HW, ntiles = (nitems + 15) / 16;
+        auto item_src = [&](int tile, int& p, int& pix) -> const float* {
+            int it = tile * 16 + i16;
+            it = it < nitems ? it : nitems - 1;
+            p = it / HW;
+            pix = it - p * HW;
+            const int y = pix / S, x = pix - y * S;
+            const int b = b0 + p < batch ? b0 + p : batch - 1;
+            return in + (size_t)b * 32 * PP + (size_t)kq * PP + (y + 1) * WP + x + 1;
+        };
+        for (int tile = wave; tile < ntiles; tile += 8) {   // two tiles (this one and tile+4) in flight
+            int p0, x0, p1, x1;
+            const float* s0 = item_src(tile, p0, x0);
+            const bool has1 = tile + 4 < ntiles;
+            const float* s1 = item_src(has1 ? tile + 4 : tile, p1, x1);
+            float bx0[8], bx1[8];
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) { bx0[s_] = s0[(size_t)(4 * s_) * PP]; bx1[s_] = s1[(size_t)(4 * s_) * PP]; }
+            f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s_], bx0[s_], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s_], bx1[s_], d1, 0, 0, 0);
+            }
+            const bool ok0 = tile * 16 + i16 < nitems, ok1 = has1 && (tile + 4) * 16 + i16 < nitems;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                  // D: col = lane&15 (item), row = kq*4 + r (co)
+                if (ok0) X[p0 * KS + (kq * 4 + r) * HW + x0] = elu1(d0[r] + bias4[r]);
+                if (ok1) X[p1 * KS + (kq * 4 + r) * HW + x1] = elu1(d1[r] + bias4[r]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    const int j0 = wave * 32 + i16, j1 = j0 + 16;
+    const float* w0 = wf + (size_t)kq * HW + (j0 < HW ? j0 : HW - 1);
+    const float* w1 = wf + (size_t)kq * HW + (j1 < HW ? j1 : HW - 1);
+    const float* xb = X + i16 * KS + kq;
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    constexpr int PF = 16;
+    float a0[PF], a1[PF];
+    const int nsteps = K / 4;                              // = 4*HW (484 at 11x11: not a multiple of PF -> tail below)
+#pragma unroll
+    for (int q = 0; q < PF; ++q) { a0[q] = w0[(size_t)q * 4 * HW]; a1[q] = w1[(size_t)q * 4 * HW]; }
+    int s0 = 0;
+    for (; s0 + PF <= nsteps; s0 += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int s_ = s0 + q;
+            const float bx = xb[s_ * 4];
+            const float ca0 = a0[q], ca1 = a1[q];
+            const int sn = s_ + PF < nsteps ? s_ + PF : nsteps - 1;   // ring slot q now waits for step s_+PF
+            a0[q] = w0[(size_t)sn * 4 * HW];
+            a1[q] = w1[(size_t)sn * 4 * HW];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca0, bx, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca1, bx, acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {                         // tail: slots 0..rem-1 hold steps s0..nsteps-1
+        if (s0 + q < nsteps) {
+            const float bx = xb[(s0 + q) * 4];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], bx, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], bx, acc1, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                       // X is dead: reuse it for the logits [16 pos][128]
+    float* Lg = smem;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                          // D: col = lane&15 (position), row = kq*4 + r
+        const int ja = wave * 32 + kq * 4 + r, jb = ja + 16;
+        Lg[i16 * 128 + ja] = acc0[r] + (ja < HW ? bf[ja] : 0.0f);
+        Lg[i16 * 128 + jb] = acc1[r] + (jb < HW ? bf[jb] : 0.0f);
+    }
+    __syncthreads();
+    // ---- phase 3 ----
+    const int p = t >> 4, sub = t & 15;                    // 16 threads per position, 8 logits each
+    float v[8], m = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = sub + 16 * q;
+        v[q] = j < HW ? Lg[p * 128 + j] : -3.0e38f;
+        m = fmaxf(m, v[q]);
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float sum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { v[q] = (sub + 16 * q) < HW ? expf(v[q] - m) : 0.0f; sum += v[q]; }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (b0 + p < batch) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = sub + 16 * q;
+            if (j < HW) policy[(size_t)(b0 + p) * HW + j] = v[q] / sum;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
@@ -905,6 +1031,8 @@ int af_net_finalize(af_net* n) {
         if (!rc) rc = net_alloc(n, &n->o[i], plane * kBlocks[i].cout, true);
     }
     if (rc) return rc;
+    NET_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_policy_head_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
     if (!n->branch_stream) {
         NET_HIP_OK(hipStreamCreateWithFlags(&n->branch_stream, hipStreamNonBlocking));
         NET_HIP_OK(hipEventCreateWithFlags(&n->ev_trunk, hipEventDisableTiming));
@@ -956,6 +1084,7 @@ extern "C" {
 
 }  // extern "C"
 
+static int g_phead = 1;          // 1: af_policy_head_mfma for boards up to 11x11; 0: VALU head
 static int g_branch = 1;         // 1: value branch on a side stream
 static int g_substreams = 1;     // >1: split the batch into that many sub-batches, one HIP stream each
 static int g_subbatch = 0;       // 0: batch / g_substreams
@@ -1012,7 +1141,12 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
             if (vs != st_main) NET_HIP_OK(hipEventRecord(n->ev_value, vs));
         }
     }
-    if (HW <= 128) {
+    if (HW <= 128 && g_phead) {
+        const int K = 16 * HW, KS = K + ((2 - K % 32) + 32) % 32;
+        const size_t lds = (size_t)16 * KS * 4;
+        hipLaunchKernelGGL(af_policy_head_mfma, dim3((batch + 15) / 16), dim3(256), lds, st, o[4], n->pc_w, n->pc_b, n->pf_w,
+                           n->pf_b, policy, batch, S, WP, PP);
+    } else if (HW <= 128) {
         const size_t lds = ((size_t)16 * HW * 8 + 512 + 32) * 4;
         hipLaunchKernelGGL((af_policy_head<8>), dim3((batch + 7) / 8), dim3(256), lds, st, o[4], n->pc_w, n->pc_b, n->pf_w,
                            n->pf_b, policy, batch, S, WP, PP);
@@ -1065,6 +1199,7 @@ int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, 
 
 int af_net_tune(int32_t cout_pad, int32_t shape) {
     if (cout_pad == 0) { g_wino = shape; return AF_NET_OK; }     // 0: conv path (2 Winograd+LDS, 1 Winograd, 0 direct)
+    if (cout_pad == 5) { g_phead = shape; return AF_NET_OK; }                       // 5: MFMA policy head (1/0)
     if (cout_pad == 4) { g_branch = shape; return AF_NET_OK; }                      // 4: value branch on a side stream (1/0)
     if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)
     if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
