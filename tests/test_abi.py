@@ -57,3 +57,17 @@ def test_error_strings_and_bad_args(lib):
         eng.Engine(make_cfg(board_size=17), 1)          # 289 cells > 256: rejected before touching HIP
     with pytest.raises(eng.EngineError):
         eng.Engine(make_cfg(goal=12), 1)
+
+
+def test_product_fails_loudly_without_a_gpu(lib):
+    """No CPU fallback: on a host without a HIP device creating an engine raises (AF_ERR_HIP)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from alphafive_amd import engine as eng
+    from conftest import make_cfg
+    with pytest.raises(eng.EngineError):
+        eng.Engine(make_cfg(), 4)
+    from alphafive_amd.player import Player
+    with pytest.raises(Exception):
+        Player(make_cfg(), training=True, pv_fn=lambda x: None)

@@ -117,3 +117,30 @@ def test_deep_bf16_evaluator_plugs_into_the_engine():
     ct = sp.counters()
     assert ct["sims"] == 512 * 39 and ct["plies"] == 512          # 30 sims -> one move each, then 10 more sims
     sp.close()
+
+
+def test_player_pipe_mode_through_networkapi_matches_pv_fn_mode():
+    """player.py:194-197 pipe protocol end to end: Player(pipe=net.get_pipes(cfg)) against the NetworkAPI
+    worker thread + ResNet.eval, vs the same search driven through pv_fn.  (The engine keeps the pv_fn
+    path's fp32 W/Q rule in both modes — DESIGN §4 — so the two must agree bit for bit.)"""
+    from alphafive_amd.network import ResNet
+    from alphafive_amd.player import Player
+    from alphafive_amd import utils
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    cfg = make_cfg(simulation_per_step=40, upper_simulation_per_step=60)
+    pipe = net.get_pipes(cfg)
+    a = Player(cfg, training=True, pipe=pipe, seed=4)
+    b = Player(cfg, training=True, pv_fn=net.eval, seed=4)
+    b._pv_device = None                      # force the host round trip so both go through ResNet.eval
+    state, last = a.get_init_state(), None
+    for _ in range(3):
+        pa, aa = a.get_action(state, last_action=last)
+        pb, ab = b.get_action(state, last_action=last)
+        assert aa == ab and (a.last_visits == b.last_visits).all()
+        assert (pa.view(np.uint32) == pb.view(np.uint32)).all()
+        board = utils.step(utils.state_to_board(state, 11), aa)
+        state, last = utils.board_to_state(board), aa
+    a.close()
+    b.close()
+    net.close()
