@@ -29,6 +29,15 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4 floats, only 4-byte aligned
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f2a __attribute__((ext_vector_type(2)));               // 8-byte aligned pair (LDS reads)
+
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS at (wave-uniform lds_dst) + lane*16; counted on
+// vmcnt, invisible to hipcc's own wait bookkeeping (callers wait with an explicit s_waitcnt vmcnt before the barrier).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 struct ConvSeg {
     const float* in;   // [batch][cin][PP]
@@ -203,27 +212,32 @@ struct WinoArgs {
     const float* bias;   // [cout]
     float* out;          // [batch][cout][PP]
     int cin, cin2, cout, ntiles, T, S, WP, PP;
+    int ntasks;          // workgroup tasks = tile-block groups (padded to 8) x cout tiles
+    int npos;            // LDSU == 2: positions a workgroup's 128 tiles can span (LDS planes per cin)
 };
 
 // LDSU = true: the U stream of the 3x3 segment is shared by the workgroup through LDS (A.u in the
 // slice layout of pack_wino_lds); false: every wave loads its own U fragments (A.u from pack_wino).
-template <bool LDSU, int ABL = 0>   // ABL (profiling only): 1 no operand loads in the 3x3 loop, 2 no input transform, 3 no k loops, 4 no epilogue
-__global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
-    __shared__ float4 su[LDSU ? 3 * 4 * 256 : 1];       // 3 buffers x 4 pair slices x 4 KB
+template <int LDSU, int ABL>        // ABL (profiling only): 1 no operand loads in the 3x3 loop, 2 no input transform, 3 no k loops, 4 no epilogue
+__device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
+    __shared__ float4 su[LDSU == 1 ? 3 * 4 * 256 : 1];  // 3 buffers x 4 pair slices x 4 KB (LDSU == 1 only)
+    extern __shared__ __attribute__((aligned(16))) char gsm[];   // LDSU == 2: 3 x (activation planes + U slices)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, kh = lane >> 5;
     const int nct = A.cout >> 5;
     // XCD-aware block -> task map: workgroup b is observed to run on XCD b % 8 and each XCD has its own L2.
     // The nct workgroups that read the SAME activations (same tile-block group, different cout tile) get the
     // block ids g8, g8+8, g8+16, ... so they share one XCD's L2 instead of fetching the planes nct times.
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int xcd = bid & 7, rest = bid >> 3;
     const int ct = rest % nct;
     const int tb = ((rest / nct) * 8 + xcd) * 4 + wave;
     const bool wave_live = tb * 32 < A.ntiles;           // (a dead wave still helps stage U and hits the barriers)
-    if (!LDSU && !wave_live) return;
+    if (LDSU == 0 && !wave_live) return;
+    const int grp = (rest / nct) * 8 + xcd;              // tile-block group = 128 consecutive tiles
+    if (LDSU == 2 && grp * 128 >= A.ntiles) return;      // whole workgroup idle (padding of the XCD interleave)
     const int q = tb * 32 + col;
     const bool valid = q < A.ntiles;
-    const int qq = valid ? q : 0;
+    const int qq = valid ? q : (LDSU == 2 ? grp * 128 : 0);
     const int TT = A.T * A.T;
     const int pos = qq / TT;
     const int t_ = qq - pos * TT;
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
     // k loops: operands ride a 4-deep register ring — the loads of phase p+3 are requested while phase p
     // computes (16 MFMAs = 1024 cycles per phase => >= 3072 cycles to land) — and the wide loads + the
     // transform adds of a phase are spread between its MFMAs by sched_group_barrier.
-    if constexpr (ABL != 3) {   // ---- 3x3 segment: phase = one cin pair (16 MFMAs) ----  (ABL 3: epilogue only)
+    if constexpr (ABL != 3 && ABL != 5 && ABL != 6) {   // ---- 3x3 segment: phase = one cin pair (16 MFMAs) ----  (ABL 3: epilogue only)
         const char* __restrict__ inb = reinterpret_cast<const char*>(A.in);
         const uint32_t boff = (uint32_t)(pos * A.cin * PP + poff0 + kh * PP) * 4u;
         const int npairs = A.cin / 2;                    // multiple of 4
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
                 M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, v[4 * x + 3], M[4 * x + 3], 0, 0, 0);
             }
         };
-        if constexpr (!LDSU) {
+        if constexpr (LDSU == 0) {
             const char* __restrict__ ub = reinterpret_cast<const char*>(A.u);
             const uint32_t woff = wlane * 64u;           // 16 floats per (kh, cout)
             float4 u0[4] = {}, u1[4] = {}, u2[4] = {}, u3[4] = {};
@@ -375,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
                     phase(c + 6, d2, u2, d3, vA, u3, vA);
                 }
             }
-        } else {
+        } else if constexpr (LDSU == 1) {
             // U through LDS: a (pair, ct) slice is 4 KB laid out [x][lane][4] (pack_wino_lds), i.e. exactly
             // one float4 per thread of the workgroup; thread t of wave w stages quad x = w.  Chunks of 4
             // pairs: chunk k+1 is written to buffer (k+1)%3 at the start of chunk k from registers whose
@@ -429,10 +443,132 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
                 phase(c + 6, d2, G[3], c + 11, bnext, 0, uA, d3, uB);
                 bcur = bnext;
             }
+        } else {
+            // LDSU == 2 — both operands through LDS, filled by LDS-DMA (global_load_lds_dwordx4, no staging registers):
+            // per chunk of 8 cin the workgroup copies the whole padded planes of the <= npos positions its 128 tiles
+            // touch (full contiguous lines instead of per-lane 4x4 patches: 2.4x fewer bytes and 2.3x fewer, fully
+            // coalesced, requests through the texture-address unit) and the 4 U slices of its cout tile (once per
+            // workgroup instead of once per wave).  3 LDS buffers: chunk i+2 is requested at the one barrier in the
+            // middle of chunk i, when every wave is done with chunk i-1.  Lanes read their patch rows (8-byte aligned
+            // ds_read_b64 pairs) two phases and their U quads (ds_read_b128, lane-linear) one phase ahead of the MFMAs.
+            const int batch = A.ntiles / TT;
+            const int p_lo = (grp * 128) / TT;
+            const uint32_t plane_b = (uint32_t)PP * 4u;
+            const uint32_t abytes = (uint32_t)A.npos * 8u * plane_b;
+            const uint32_t bufb = abytes + 16384u;
+            const uint32_t nunits = abytes >> 4;                 // 16-byte units of activations per chunk
+            const uint32_t upp = plane_b >> 1;                   // units per position (8 planes)
+            const uint32_t lds0 = (uint32_t)(uintptr_t)gsm;      // low 32 bits of a generic LDS pointer = LDS byte address
+            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            uint32_t asrc[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const uint32_t un_ = (uint32_t)j * 256u + threadIdx.x;
+                const uint32_t pi = un_ / upp, off = un_ - pi * upp;
+                int gp = p_lo + (int)pi;
+                gp = gp < batch ? gp : batch - 1;
+                asrc[j] = (uint32_t)gp * (uint32_t)A.cin * plane_b + off * 16u;
+            }
+            const char* __restrict__ usrc = reinterpret_cast<const char*>(A.u) + (size_t)ct * 4096 + threadIdx.x * 16u;
+            const size_t ustride = (size_t)nct * 4096;
+            auto stage = [&](int k, uint32_t bo) {               // chunk k -> the buffer at byte offset bo
+                const uint32_t coff = (uint32_t)k * 8u * plane_b;
+                const uint32_t wdst = lds0 + bo + wv * 1024u;
+#pragma unroll
+                for (int j = 0; j < 9; ++j)
+                    if ((uint32_t)j * 256u + threadIdx.x < nunits)
+                        glds16(inb + (size_t)(asrc[j] + coff), (uint32_t)__builtin_amdgcn_readfirstlane((int)(wdst + (uint32_t)j * 4096u)));
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    glds16(usrc + (size_t)(4 * k + p) * ustride,
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(wdst + abytes + (uint32_t)p * 4096u)));
+            };
+            const uint32_t la = ((uint32_t)(pos - p_lo) * 8u + (uint32_t)kh) * plane_b + (uint32_t)poff0 * 4u;
+            const uint32_t lu = abytes + (uint32_t)lane * 16u;
+            auto rd_d = [&](uint32_t bo, int p, f4u (&d)[4]) {   // patch of pair p of the chunk in buffer bo
+                const char* b = gsm + (bo + la + (uint32_t)(2 * p) * plane_b);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f2a lo = *reinterpret_cast<const f2a*>(b + r * WP * 4);
+                    const f2a hi = *reinterpret_cast<const f2a*>(b + r * WP * 4 + 8);
+                    d[r][0] = lo[0]; d[r][1] = lo[1]; d[r][2] = hi[0]; d[r][3] = hi[1];
+                }
+            };
+            auto rd_u = [&](uint32_t bo, int p, float4 (&u)[4]) {
+                const char* b = gsm + (bo + lu + (uint32_t)p * 4096u);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) u[x] = *reinterpret_cast<const float4*>(b + x * 1024);
+            };
+            auto transform = [&](f4u (&d)[4], float (&v)[16]) {
+                float t[16];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    t[0 + s_] = d[0][s_] - d[2][s_];
+                    t[4 + s_] = d[1][s_] + d[2][s_];
+                    t[8 + s_] = d[2][s_] - d[1][s_];
+                    t[12 + s_] = d[1][s_] - d[3][s_];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
+                    v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+                    v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+                    v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+                }
+            };
+            auto mfma16 = [&](float4 (&u)[4], float (&v)[16]) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    M[4 * x + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].x, v[4 * x + 0], M[4 * x + 0], 0, 0, 0);
+                    M[4 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].y, v[4 * x + 1], M[4 * x + 1], 0, 0, 0);
+                    M[4 * x + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].z, v[4 * x + 2], M[4 * x + 2], 0, 0, 0);
+                    M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, v[4 * x + 3], M[4 * x + 3], 0, 0, 0);
+                }
+            };
+            f4u dA[4], dB[4];
+            float4 uA[4], uB[4];
+            float vA[16], vB[16];
+            // phase j: multiply pair j, transform pair j+1, read the patch of pair j+2 and the U quads of pair j+1
+            auto phase = [&](uint32_t bo_d, int p_d, f4u (&dl)[4], uint32_t bo_u, int p_u, float4 (&ul)[4], f4u (&dn)[4],
+                             float (&vn)[16], float4 (&uc)[4], float (&vc)[16]) {
+                rd_d(bo_d, p_d, dl);
+                rd_u(bo_u, p_u, ul);
+                transform(dn, vn);
+                mfma16(uc, vc);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            const int nchunks = A.cin / 8;                       // >= 4
+            stage(0, 0u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage(1, bufb);
+            rd_d(0u, 0, dA); rd_d(0u, 1, dB); rd_u(0u, 0, uA);
+            transform(dA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t bc = 0u, bn = bufb, bf = 2u * bufb;         // buffers of chunk i, i+1 and the free one
+            for (int i = 0; i < nchunks; ++i) {
+                phase(bc, 2, dA, bc, 1, uB, dB, vB, uA, vA);
+                phase(bc, 3, dB, bc, 2, uA, dA, vA, uB, vB);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk i+1 (requested one chunk ago) has landed
+                __builtin_amdgcn_s_barrier();                       // ... for every wave; all are done with chunk i-1
+                if (i + 2 < nchunks) stage(i + 2, bf);
+                __builtin_amdgcn_sched_barrier(0);
+                phase(bn, 0, dA, bc, 3, uB, dB, vB, uA, vA);
+                phase(bn, 1, dB, bn, 0, uA, dA, vA, uB, vB);
+                const uint32_t t_ = bc; bc = bn; bn = bf; bf = t_;
+            }
         }
     }
     if (!wave_live) return;
-    if (ABL != 3 && A.in2) {   // ---- 1x1 projection segment: phase = 4 cin pairs (16 MFMAs) ----
+    if (ABL != 3 && ABL != 5 && ABL != 6 && A.in2) {   // ---- 1x1 projection segment: phase = 4 cin pairs (16 MFMAs) ----
         const char* __restrict__ inb = reinterpret_cast<const char*>(A.in2);
         const char* __restrict__ ub = reinterpret_cast<const char*>(A.u2);
         const uint32_t boff = (uint32_t)(pos * A.cin2 * PP + poff0 + kh * PP + WP + 1) * 4u;   // patch centre (1,1)
@@ -492,6 +628,12 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
         if (sink == 12345.678f) A.out[0] = sink;
         return;
     }
+    if constexpr (ABL == 6) {          // profiling: the same bytes as the epilogue, as fully coalesced 16-byte stores
+        float4* o4 = reinterpret_cast<float4*>(A.out) + ((size_t)(bid * 4 + wave) * 1024 + lane);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o4[i * 64] = make_float4(bias_r[i], bias_r[i], bias_r[i], bias_r[i]);
+        return;
+    }
     // ---- output transform Y = A^T M A, bias, ELU, store the 2x2 tile ----
     // (bias values were requested before the k loops; each tile row goes out as one 8-byte store, so the
     // lanes of a board row write one contiguous run)
@@ -511,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
         y0[0] = elu1(s0[0] + s0[1] + s0[2] + bv); y0[1] = elu1(s0[1] - s0[2] - s0[3] + bv);
         y1[0] = elu1(s1[0] + s1[1] + s1[2] + bv); y1[1] = elu1(s1[1] - s1[2] - s1[3] + bv);
         float* o = obase + (size_t)co * PP;
-        if (valid) {
+        if (ABL == 5 ? (valid && y0[0] == 12345.678f) : valid) {   // ABL 5 (profiling): no k loops and no stores
             if (ok1x) {
                 *reinterpret_cast<f2u*>(o) = y0;
                 if (ok1y) *reinterpret_cast<f2u*>(o + WP) = y1;
@@ -520,6 +662,18 @@ __global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
                 if (ok1y) o[WP] = y1[0];
             }
         }
+    }
+}
+
+// PERSIST: one workgroup per CU walks the task list with stride gridDim.x (a multiple of 8, so a workgroup's
+// tasks stay on its XCD): the stores of task i drain while task i+1 runs instead of holding the CU until the
+// workgroup retires, and there is no per-round dispatch gap.
+template <int LDSU, int ABL = 0, bool PERSIST = false>
+__global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
+    if constexpr (PERSIST) {
+        for (int t = blockIdx.x; t < A.ntasks; t += gridDim.x) wino_task<LDSU, ABL>(A, t);
+    } else {
+        wino_task<LDSU, ABL>(A, blockIdx.x);
     }
 }
 
@@ -1033,6 +1187,8 @@ int af_net_finalize(af_net* n) {
     if (rc) return rc;
     NET_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_policy_head_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
+    NET_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_wino<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
     if (!n->branch_stream) {
         NET_HIP_OK(hipStreamCreateWithFlags(&n->branch_stream, hipStreamNonBlocking));
         NET_HIP_OK(hipEventCreateWithFlags(&n->ev_trunk, hipEventDisableTiming));
@@ -1045,22 +1201,39 @@ int af_net_finalize(af_net* n) {
 }  // extern "C"
 
 static int g_abl = 0;    // profiling: ablation variant of af_conv_wino<false>
+static int g_pgrid = 256; // workgroups of the persistent variant (g_wino == 4)
 static int g_wino = 1;   // 1: af_conv_wino<false> (default); 2: af_conv_wino<true> (U through LDS: measured 6 % slower); 0: direct af_conv_mfma
 
-static void launch_wino(hipStream_t st, const af_net* n, int batch, const float* in, const float* u, int cin,
+static void launch_wino(hipStream_t st, const af_net* n, int batch, const float* in, const float* u, const float* ul, int cin,
                         const float* in2, const float* u2, int cin2, const float* bias, float* out, int cout) {
     WinoArgs a;
-    a.in = in; a.u = u; a.in2 = in2; a.u2 = u2; a.bias = bias; a.out = out;
+    a.in = in; a.u = g_wino == 2 ? ul : u; a.in2 = in2; a.u2 = u2; a.bias = bias; a.out = out;
     a.cin = cin; a.cin2 = cin2; a.cout = cout; a.T = n->T; a.S = n->S; a.WP = n->WP; a.PP = n->PP;
     a.ntiles = batch * n->T * n->T;
     const int ntb = (a.ntiles + 31) / 32;
     const int ngrp8 = (((ntb + 3) / 4) + 7) / 8 * 8;      // tile-block groups, padded to the 8-XCD interleave
-    if (g_wino == 2) hipLaunchKernelGGL((af_conv_wino<true, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 1) hipLaunchKernelGGL((af_conv_wino<false, 1>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 4) hipLaunchKernelGGL((af_conv_wino<false, 4>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 3) hipLaunchKernelGGL((af_conv_wino<false, 3>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 2) hipLaunchKernelGGL((af_conv_wino<false, 2>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((af_conv_wino<false, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    // LDS-DMA path: needs the staging loop's 9 rounds and 3 buffers of (npos x 8 planes + 16 KB of U) to fit
+    a.npos = 127 / (n->T * n->T) + 2;
+    const size_t gl_bytes = 3 * ((size_t)a.npos * 8 * n->PP * 4 + 16384);
+    const bool gl_ok = (size_t)a.npos * 8 * n->PP * 4 / 16 <= 9 * 256 && gl_bytes <= 160 * 1024 && cin % 8 == 0 && cin >= 32;
+    if (g_wino == 3 && gl_ok && g_abl == 0) {
+        a.u = ul;
+        hipLaunchKernelGGL((af_conv_wino<2, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), gl_bytes, st, a);
+        return;
+    }
+    a.ntasks = ngrp8 * (cout / 32);
+    if (g_wino == 4 && g_abl == 0) {
+        hipLaunchKernelGGL((af_conv_wino<0, 0, true>), dim3(a.ntasks < g_pgrid ? a.ntasks : g_pgrid), dim3(256), 0, st, a);
+        return;
+    }
+    if (g_wino == 2) hipLaunchKernelGGL((af_conv_wino<1, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 1) hipLaunchKernelGGL((af_conv_wino<0, 1>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 4) hipLaunchKernelGGL((af_conv_wino<0, 4>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 3) hipLaunchKernelGGL((af_conv_wino<0, 3>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 6) hipLaunchKernelGGL((af_conv_wino<0, 6>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 5) hipLaunchKernelGGL((af_conv_wino<0, 5>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else if (g_abl == 2) hipLaunchKernelGGL((af_conv_wino<0, 2>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((af_conv_wino<0, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
 }
 
 template <int NT, int MT, int MINW>
@@ -1118,9 +1291,9 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
         hipStream_t st = (i == 2) ? vs : st_main;
         if (g_wino) {
             // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
-            launch_wino(st, n, batch, block_in[i], g_wino == 2 ? n->wino1_ul[i] : n->wino1_u[i], b.cin, nullptr, nullptr, 0,
+            launch_wino(st, n, batch, block_in[i], n->wino1_u[i], n->wino1_ul[i], b.cin, nullptr, nullptr, 0,
                         n->conv1_b[i], g[i], b.cout);
-            launch_wino(st, n, batch, g[i], g_wino == 2 ? n->wino2_ul[i] : n->wino2_u[i], b.cout, block_in[i], n->winor_u[i], b.cin,
+            launch_wino(st, n, batch, g[i], n->wino2_u[i], n->wino2_ul[i], b.cout, block_in[i], n->winor_u[i], b.cin,
                         n->sum_b[i], o[i], b.cout);
         } else {
             ConvArgs a;
@@ -1199,6 +1372,7 @@ int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, 
 
 int af_net_tune(int32_t cout_pad, int32_t shape) {
     if (cout_pad == 0) { g_wino = shape; return AF_NET_OK; }     // 0: conv path (2 Winograd+LDS, 1 Winograd, 0 direct)
+    if (cout_pad == 6) { g_pgrid = shape; return AF_NET_OK; }                       // 6: persistent-grid size
     if (cout_pad == 5) { g_phead = shape; return AF_NET_OK; }                       // 5: MFMA policy head (1/0)
     if (cout_pad == 4) { g_branch = shape; return AF_NET_OK; }                      // 4: value branch on a side stream (1/0)
     if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)

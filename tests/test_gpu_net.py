@@ -82,7 +82,8 @@ def test_flop_count_matches_survey():
 
 
 def test_alternate_conv_paths_agree_with_fp64():
-    """The direct implicit-GEMM path (af_net_tune(0,0)) and the LDS-shared-U Winograd path (0,2) stay correct."""
+    """The direct implicit-GEMM path (af_net_tune(0,0)), the LDS-shared-U Winograd path (0,2) and the LDS-DMA
+    Winograd path (0,3) stay correct."""
     import torch
     from alphafive_amd import net_hip
     from alphafive_amd.network import ResNet
@@ -93,7 +94,7 @@ def test_alternate_conv_paths_agree_with_fp64():
     xt = torch.from_numpy(x).cuda()
     p64, v64 = net_fp64.forward(net.variables, x[:32])
     try:
-        for mode in (0, 2, 1):
+        for mode in (0, 2, 3, 4, 1):
             net_hip.tune(0, mode)
             p, v = pv(xt)
             assert np.abs(v[:32].cpu().numpy() - v64).max() < 1e-5, mode

@@ -30,7 +30,7 @@ for name, fn in (("torch", net.eval_device), ("hip", pv)):
 if os.environ.get("TUNES"):
     from alphafive_amd import net_hip
     for spec in os.environ["TUNES"].split(";"):
-        net_hip.tune(0, 1); net_hip.tune(3, 0); net_hip.tune(4, 1); net_hip.tune(1, 1)
+        net_hip.tune(0, 1); net_hip.tune(3, 0); net_hip.tune(4, 1); net_hip.tune(1, 1); net_hip.tune(6, 256)
         for kv in spec.split(","):
             if kv: net_hip.tune(int(kv.split(":")[0]), int(kv.split(":")[1]))
         for _ in range(5): pv(xt)

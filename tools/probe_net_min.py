@@ -8,6 +8,9 @@ B = int(os.environ.get("B", 4096)); N = int(os.environ.get("N", 3))
 net = ResNet(11, device="cuda", seed=1); net.load_npz(os.path.join(R, "tests/golden/alphaFive-6960.weights.npz"))
 x = (torch.rand((B, 3, 11, 11), device="cuda") < 0.2).float()
 pv = net.select_backend("hip")
+if os.environ.get("MODE"):
+    from alphafive_amd import net_hip
+    net_hip.tune(0, int(os.environ["MODE"]))
 for _ in range(N): pv(x)
 torch.cuda.synchronize()
 print("done")
