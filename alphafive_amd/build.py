@@ -18,6 +18,7 @@ HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared"
 TARGETS = {
     "libaf_hip.so": (["csrc/af_engine.hip"], ["-ffp-contract=off"]),
     "libaf_net.so": (["csrc/af_net.hip"], []),
+    "libaf_tower.so": (["csrc/af_tower_bf16.hip"], []),
 }
 
 

@@ -1,0 +1,328 @@
+// af_tower_bf16.hip — bf16 residual tower for gfx950 (C ABI: include/af_tower_bf16.h).
+//
+// One kernel, af_tower_conv<PROJ>, is a 3x3 convolution 128 -> 128 over 11x11 boards as an implicit GEMM
+//   out[cout][pixel] = sum_{tap, cin} W[cout][cin][tap] * in[cin][pixel + tap offset]
+// on v_mfma_f32_32x32x16_bf16 (M = 32 couts, N = 32 pixels, K = 16 cin of one tap), plus, for the second
+// convolution of a block (PROJ), 8 more k-steps that fold the block's 1x1 projection of the block input in.
+//
+// Work split (weight-stationary, persistent): a workgroup = 4 waves = the 4 cout tiles of 32; each wave keeps
+// ALL its weights — 32 couts x (9*128 [+128]) k = 72 [80] A fragments of 8 bf16 = 288 [320] registers — resident
+// for the whole launch (one wave per SIMD, 512-register budget) and the workgroup walks over positions with
+// stride gridDim.x.  A position's activations (36 KB in the C8 layout, include/af_tower_bf16.h) are copied
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: contiguous, no staging registers), double buffered:
+// position i+1 lands while position i multiplies.  In C8, a B fragment (32 pixels x 16 cin) is one
+// ds_read_b128 per lane at lane_base + compile-time offset (pixel units are 16 bytes, consecutive pixels are
+// consecutive units => conflict-free; a row's missing left/right neighbours are zeroed by lane masks), so the inner
+// loop is ds_read_b128 + MFMA (+ 4 v_cndmask on two taps out of three).
+// Epilogue: bias, ELU, round to bf16, 8-byte stores that pair up (k halves) into contiguous 512-byte runs.
+//
+// Roofline: 2*128*128*9*121 = 35.7 MFLOP per position and convolution on 2.5 PFLOP/s dense bf16 MFMA;
+// per position a workgroup reads 36 KB (+36 KB PROJ) and writes 31 KB of HBM: 8192 positions x 16 convolutions
+// = 4.7 TFLOP and ~11 GB per tower pass, i.e. MFMA-bound (1.9 ms) over HBM (1.4 ms at 8 TB/s) by a small margin.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "af_tower_bf16.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TW_HIP_OK(expr)                                      \
+    do {                                                     \
+        hipError_t err_ = (expr);                            \
+        if (err_ != hipSuccess) return AF_TOWER_ERR_HIP;     \
+    } while (0)
+
+// LDS-DMA: 16 bytes per lane from global memory into LDS at (wave-uniform lds_dst) + lane*16; counted on vmcnt.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+
+struct TowerArgs {
+    const char* in;      // C8 bf16 [batch][16][PIX][8]: input of the 3x3 convolution
+    const char* in2;     // PROJ: block input (1x1 projection), same layout
+    const uint4* w;      // [4 waves][NS][64 lanes] A fragments (8 bf16)
+    const float* bias;   // [128]
+    char* out;           // C8 bf16
+    int batch;
+    int abl;             // profiling: bit 0 = stage only the first position, bit 1 = no stores, bit 2 = no ELU
+};
+
+constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;                    // 13 rows x 11 pixels (+1): pixel n sits at unit n + 11
+constexpr uint32_t kPlaneB = 16u * kPIX * 16u;                          // 36,864 bytes per position
+constexpr int kRounds = kPlaneB / (256 * 16);                           // 9 LDS-DMA rounds of 256 lanes x 16 B
+constexpr uint32_t kLds0 = 256u;                                        // planes start here: unit -1 of a plane stays inside LDS
+
+template <bool PROJ, int DEPTH>
+__global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // [256 B][g0][g1]([h])
+    constexpr int NS = PROJ ? 80 : 72;
+    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem + kLds0;
+
+    auto stage = [&](const char* src, int pos, uint32_t off) {          // one position's plane -> LDS at byte offset off
+        const char* s = src + (size_t)pos * kPlaneB + threadIdx.x * 16u;
+        const uint32_t d = lds0 + off + wv * 1024u;
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) glds16(s + r * 4096, (uint32_t)__builtin_amdgcn_readfirstlane((int)(d + r * 4096u)));
+    };
+    int pos = blockIdx.x;
+    if (pos >= A.batch) return;
+    stage(A.in, pos, 0u);
+    if (PROJ) stage(A.in2, pos, 2u * kPlaneB);
+
+    // resident weights and bias
+    bf16x8 W[NS];
+    {
+        const uint4* wp = A.w + ((size_t)wv * NS * 64 + lane);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint4 v = wp[s * 64];
+            __builtin_memcpy(&W[s], &v, 16);
+        }
+    }
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = A.bias[32 * wv + 8 * (r >> 2) + 4 * kg + (r & 3)];
+
+    // the lane's pixel in each of the 4 pixel tiles: LDS byte base of tap (0,0) (one row up, one pixel left).  Rows are
+    // stored back to back (no pad columns: consecutive lanes read consecutive 16-byte units, which is what keeps
+    // ds_read_b128 conflict-free), so the left / right taps of the first / last pixel of a row are zeroed by lane masks.
+    uint32_t lb[4], ob[4];
+    bool ok[4], edgeL[4], edgeR[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = 32 * j + nn;
+        ok[j] = n < kNPIX;
+        const int nc = ok[j] ? n : 0;
+        const int x = nc % kS;
+        edgeL[j] = x == 0; edgeR[j] = x == kS - 1;
+        lb[j] = kLds0 + (uint32_t)(kg * kPIX + nc + kS - (kS + 1)) * 16u;
+        ob[j] = (uint32_t)(nc + kS) * 16u + (uint32_t)kg * 8u;          // output unit of the pixel + this lane's k half
+    }
+    // Pin the weight / bias loads' completion HERE: hipcc otherwise sinks its counted vmcnt waits to the first use of
+    // each fragment inside the position loop, where they would also wait for the (to hipcc invisible) LDS-DMA of the
+    // next position that is issued at the top of every iteration.
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(W[s]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bias_r[r]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int it = 0; pos < A.batch; pos += gridDim.x, ++it) {
+        const uint32_t gcur = (it & 1) ? kPlaneB : 0u, gnxt = kPlaneB - gcur;
+        const int nxt = pos + (int)gridDim.x;
+        const bool more = nxt < A.batch && !(A.abl & 1);
+        if (more) stage(A.in, nxt, gnxt);
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        // MFMA i of the position: pixel tile j = i % 4 of k-step i / 4; PROJ runs its 8 projection steps (block-input
+        // plane) first.  B fragments ride a DEPTH-deep register ring: the ds_read_b128 of MFMA i + DEPTH is issued
+        // right after MFMA i, so an LDS read has DEPTH MFMAs (32 cycles each) to land.
+        constexpr int NM = NS * 4, NPJ = PROJ ? 32 : 0;
+        auto rd = [&](int i) -> bf16x8 {
+            const int j = i & 3;
+            if (i < NPJ) {
+                const int cc = i >> 2;
+                return *reinterpret_cast<const bf16x8*>(smem + 2u * kPlaneB + lb[j] + (uint32_t)(2 * cc * kPIX + kS + 1) * 16u);
+            }
+            const int s_ = (i - NPJ) >> 2, t = s_ >> 3, cc = s_ & 7;
+            return *reinterpret_cast<const bf16x8*>(smem + gcur + lb[j] + (uint32_t)(2 * cc * kPIX + (t / 3) * kS + (t % 3)) * 16u);
+        };
+        bf16x8 ring[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) ring[i] = rd(i);
+#pragma clang loop unroll(full)
+        for (int i = 0; i < NM; ++i) {
+            const int ws = i < NPJ ? 72 + (i >> 2) : (i - NPJ) >> 2;
+            bf16x8 bfr = ring[i % DEPTH];
+            if (i >= NPJ) {
+                const int dx = (((i - NPJ) >> 2) >> 3) % 3;
+                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (dx == 0) bfr = edgeL[i & 3] ? zero : bfr;
+                if (dx == 2) bfr = edgeR[i & 3] ? zero : bfr;
+            }
+            acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[ws], bfr, acc[i & 3], 0, 0, 0);
+            if (i + DEPTH < NM && !(A.abl & 8)) ring[i % DEPTH] = rd(i + DEPTH);   // abl bit 3 (profiling): no LDS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            if (PROJ && i == NPJ - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                    // every wave is done with the projection plane
+                if (more) stage(A.in2, nxt, 2u * kPlaneB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the next position's planes have landed ...
+        __builtin_amdgcn_s_barrier();                                   // ... for every wave, and all are done with this one
+        // epilogue: bias, ELU, bf16, store (cout block = 4*wave + r/4; 4 consecutive couts per lane = 8 bytes)
+        char* const o = A.out + (size_t)pos * kPlaneB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (__bf16)elu1(acc[j][4 * q + e] + bias_r[4 * q + e]);
+                if (ok[j] && !(A.abl & 2)) *reinterpret_cast<bf16x4*>(o + (uint32_t)((4 * wv + q) * kPIX) * 16u + ob[j]) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------ host ------------------------------------------------------------------
+struct af_tower {
+    int S = 0, width = 0, blocks = 0, device = 0;
+    std::vector<uint4*> w1, w2;
+    std::vector<float*> b1, b2;
+    std::vector<char> set;
+};
+
+static uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// A fragments: [wave][s][lane][e] = W[cout = 32*wave + (lane&31)][cin = 16*cc + 8*(lane>>5) + e][tap t], s = 8*t + cc;
+// s = 72 + cc: the 1x1 projection.
+static std::vector<uint16_t> pack_tower(const float* w3, const float* w1x1) {
+    const int NS = w1x1 ? 80 : 72;
+    std::vector<uint16_t> out((size_t)4 * NS * 64 * 8);
+    for (int wv = 0; wv < 4; ++wv)
+        for (int s = 0; s < NS; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = 32 * wv + (lane & 31);
+                    const int cc = s < 72 ? s % 8 : s - 72;
+                    const int ci = 16 * cc + 8 * (lane >> 5) + e;
+                    const float v = s < 72 ? w3[((size_t)co * 128 + ci) * 9 + s / 8] : w1x1[(size_t)co * 128 + ci];
+                    out[(((size_t)wv * NS + s) * 64 + lane) * 8 + e] = bf16_rne(v);
+                }
+    return out;
+}
+
+template <class T>
+static int upload(T** dst, const void* src, size_t bytes) {
+    if (*dst) (void)hipFree(*dst);
+    *dst = nullptr;
+    TW_HIP_OK(hipMalloc(reinterpret_cast<void**>(dst), bytes));
+    TW_HIP_OK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return AF_TOWER_OK;
+}
+
+static int g_depth = 0;     // B-fragment ring depth (A/B knob; 0 = per-kernel default)
+static int g_abl = 0;       // profiling ablations (results wrong by design)
+static int g_grid = 0;      // persistent workgroups (0 = one per CU)
+
+extern "C" {
+
+int af_tower_tune(int32_t key, int32_t value) {
+    if (key == 0) { g_depth = value; return AF_TOWER_OK; }
+    if (key == 1) { g_grid = value; return AF_TOWER_OK; }
+    if (key == 2) { g_abl = value; return AF_TOWER_OK; }
+    return AF_TOWER_ERR_ARG;
+}
+
+const char* af_tower_strerror(int code) {
+    switch (code) {
+        case AF_TOWER_OK: return "ok";
+        case AF_TOWER_ERR_ARG: return "bad argument";
+        case AF_TOWER_ERR_HIP: return "HIP runtime error";
+        case AF_TOWER_ERR_STATE: return "not every block has weights";
+        default: return "unknown error";
+    }
+}
+
+int af_tower_create(int32_t S, int32_t width, int32_t blocks, int32_t device, af_tower** out) {
+    if (!out || S != kS || width != 128 || blocks < 1) return AF_TOWER_ERR_ARG;
+    TW_HIP_OK(hipSetDevice(device));
+    af_tower* t = new af_tower();
+    t->S = S; t->width = width; t->blocks = blocks; t->device = device;
+    t->w1.assign(blocks, nullptr); t->w2.assign(blocks, nullptr);
+    t->b1.assign(blocks, nullptr); t->b2.assign(blocks, nullptr);
+    t->set.assign(blocks, 0);
+#define TW_ATTR(P, D) TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv<P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    TW_ATTR(false, 8); TW_ATTR(true, 8); TW_ATTR(false, 12); TW_ATTR(true, 12); TW_ATTR(false, 16); TW_ATTR(true, 16);
+#undef TW_ATTR
+    *out = t;
+    return AF_TOWER_OK;
+}
+
+void af_tower_destroy(af_tower* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    for (auto p : t->w1) if (p) (void)hipFree(p);
+    for (auto p : t->w2) if (p) (void)hipFree(p);
+    for (auto p : t->b1) if (p) (void)hipFree(p);
+    for (auto p : t->b2) if (p) (void)hipFree(p);
+    delete t;
+}
+
+int af_tower_set_block(af_tower* t, int32_t b, const float* c1_w, const float* c1_b, const float* c2_w, const float* c2_b,
+                       const float* res_w, const float* res_b) {
+    if (!t || b < 0 || b >= t->blocks || !c1_w || !c1_b || !c2_w || !c2_b || !res_w || !res_b) return AF_TOWER_ERR_ARG;
+    TW_HIP_OK(hipSetDevice(t->device));
+    const std::vector<uint16_t> p1 = pack_tower(c1_w, nullptr), p2 = pack_tower(c2_w, res_w);
+    std::vector<float> bb(128);
+    int rc = upload(&t->w1[b], p1.data(), p1.size() * 2);
+    if (!rc) rc = upload(&t->w2[b], p2.data(), p2.size() * 2);
+    if (!rc) rc = upload(&t->b1[b], c1_b, 128 * 4);
+    for (int i = 0; i < 128; ++i) bb[i] = c2_b[i] + res_b[i];
+    if (!rc) rc = upload(&t->b2[b], bb.data(), 128 * 4);
+    if (!rc) t->set[b] = 1;
+    return rc;
+}
+
+int32_t af_tower_pix(const af_tower*) { return kPIX; }
+int64_t af_tower_plane_elems(const af_tower*) { return (int64_t)128 * kPIX; }
+
+int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_t batch) {
+    if (!t || !x_dev || !g_dev || batch < 1) return AF_TOWER_ERR_ARG;
+    for (char c : t->set) if (!c) return AF_TOWER_ERR_STATE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int dev = 0, ncu = 256;
+    TW_HIP_OK(hipGetDevice(&dev));
+    TW_HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (g_grid > 0) ncu = g_grid;
+    const int grid = batch < ncu ? batch : ncu;
+    for (int b = 0; b < t->blocks; ++b) {
+        TowerArgs a;
+        a.batch = batch; a.abl = g_abl;
+        const char* xin = static_cast<const char*>(x_dev);
+        a.in = xin; a.in2 = nullptr; a.w = t->w1[b]; a.bias = t->b1[b]; a.out = static_cast<char*>(g_dev);
+        // ring depth per kernel: the deepest that hipcc allocates without scratch (a scratch reload's vmcnt(0) would
+        // also wait for the LDS-DMA of the next position: measured 400 vs 230 us per launch)
+        const int d1 = g_depth ? g_depth : 12, d2 = g_depth ? g_depth : 8;
+        if (d1 == 16) hipLaunchKernelGGL((af_tower_conv<false, 16>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB, st, a);
+        else if (d1 == 12) hipLaunchKernelGGL((af_tower_conv<false, 12>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB, st, a);
+        else hipLaunchKernelGGL((af_tower_conv<false, 8>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB, st, a);
+        a.in = static_cast<const char*>(g_dev); a.in2 = xin; a.w = t->w2[b]; a.bias = t->b2[b];
+        a.out = static_cast<char*>(x_dev);
+        if (d2 == 16) hipLaunchKernelGGL((af_tower_conv<true, 16>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB, st, a);
+        else if (d2 == 12) hipLaunchKernelGGL((af_tower_conv<true, 12>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB, st, a);
+        else hipLaunchKernelGGL((af_tower_conv<true, 8>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB, st, a);
+    }
+    TW_HIP_OK(hipGetLastError());
+    return AF_TOWER_OK;
+}
+
+int64_t af_tower_flops_per_position(const af_tower* t) {
+    return (int64_t)2 * t->blocks * (128 * 128 * 9 * 2 + 128 * 128) * kNPIX;
+}
+
+}  // extern "C"

@@ -1,6 +1,8 @@
 """BASELINE configs[4]: a deeper policy/value net — N residual blocks of the reference's block type
 (network.py:52-56: 1x1 projection || 3x3+ELU -> 3x3, add, ELU) at constant width, the reference's two heads,
-evaluated in bf16 on PyTorch-ROCm ops.  Performance-only configuration (no checkpoint exists for
+evaluated in bf16.  The residual tower (99 % of the FLOPs) runs on the hand-written MFMA kernel of
+csrc/af_tower_bf16.hip (`select_backend("hip")`, the bench default); the 5x5 stem and the two heads stay on
+PyTorch-ROCm ops, as does the all-torch reference path `eval_device`.  Performance-only configuration (no checkpoint exists for
 it, random init, no bit parity); it plugs into SelfPlayEngine through the same
 planes[G,3,S,S] -> (prob[G,C], value[G]) evaluator seam as the fp32 net.
 """
@@ -49,3 +51,37 @@ class DeepResNet(object):
         p = F.elu(F.conv2d(h, *self.pconv)).reshape(B, -1)
         p = torch.softmax((p @ self.pfc[0] + self.pfc[1]).float(), dim=1)
         return p, v
+
+    # ---- hand-written tower (csrc/af_tower_bf16.hip) ----
+    def select_backend(self, name, max_batch):
+        """"hip": torch stem -> af_tower_forward -> torch heads (raises if libaf_tower.so is missing);
+        "torch": the all-PyTorch path."""
+        if name == "torch":
+            return self.eval_device
+        if name != "hip":
+            raise ValueError(name)
+        from . import tower_hip
+        self._tower = tower_hip.HipTower(self.tower, self.board_size, self.width, max_batch, self.device)
+        return self.eval_hip
+
+    @torch.no_grad()
+    def eval_hip(self, x):
+        B, tw = x.shape[0], self._tower
+        tw.load_nchw(F.elu(F.conv2d(x.to(self.dtype), self.stem[0], self.stem[1], padding=2)))
+        tw.forward(B)
+        h = tw.store_nchw(B)
+        v = F.elu(F.conv2d(h, *self.vconv)).reshape(B, -1)
+        v = F.elu(v @ self.vfc1[0] + self.vfc1[1])
+        v = torch.tanh((v @ self.vfc2[0] + self.vfc2[1]).float() / 2).squeeze(1)
+        p = F.elu(F.conv2d(h, *self.pconv)).reshape(B, -1)
+        p = torch.softmax((p @ self.pfc[0] + self.pfc[1]).float(), dim=1)
+        return p, v
+
+    @torch.no_grad()
+    def tower_reference(self, h):
+        """The tower alone on PyTorch ops (bf16 in/out NCHW) — what af_tower_forward replaces."""
+        for blk in self.tower:
+            r = F.conv2d(h, *blk["res"])
+            g = F.elu(F.conv2d(h, *blk["c1"], padding=1))
+            h = F.elu(r + F.conv2d(g, *blk["c2"], padding=1))
+        return h

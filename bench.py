@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--net", default="auto", choices=["auto", "torch", "hip", "deep-bf16"],
+    ap.add_argument("--net", default="auto", choices=["auto", "torch", "hip", "deep-bf16", "deep-bf16-torch"],
                     help="deep-bf16 = BASELINE configs[4]: 8-block width-128 net in bf16 (use with --games 8192)")
     args = ap.parse_args()
 
@@ -130,10 +130,10 @@ def main():
     if world > 1:
         afdist.broadcast_weights(net, src=0)      # one 3 MB broadcast, as a weight update would do
     deep = None
-    if args.net == "deep-bf16":
+    if args.net.startswith("deep-bf16"):
         from alphafive_amd.network_deep import DeepResNet
         deep = DeepResNet(cfg.board_size, blocks=8, width=128, device=dev)
-        pv = deep.eval_device
+        pv = deep.select_backend("torch" if args.net.endswith("torch") else "hip", G)   # "hip" raises without libaf_tower.so
     else:
         pv = net.select_backend(args.net)
     sp = SelfPlayEngine(cfg, G, pv, device=local, seed=args.seed, first_game_id=rank * G)
@@ -229,8 +229,10 @@ def main():
                 traffic_tick = prof["tick_kernel_bytes_per_launch"]["corrected"]
                 traffic_src = "profiles/r1_08_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         if deep is not None:
-            roof = {"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
-                    "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"}
+            roof = ({"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
+                     "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"} if args.net.endswith("torch") else
+                    {"backend": "hip (af_tower_bf16.hip: bf16 MFMA implicit-GEMM tower, weight-stationary, LDS-DMA staging) + torch stem/heads",
+                     "kernel": "deep net forward = torch stem + 16x af_tower_conv + torch heads (whole forward timed; the tower carries 99 % of the FLOPs)"})
         out = {
             "metric": "self-play moves/sec (%dx%d, %d sims/move)" % (cfg.board_size, cfg.board_size, args.sims), "value": total_plies / t, "unit": "moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps,

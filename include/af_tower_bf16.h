@@ -1,0 +1,58 @@
+/*
+ * af_tower_bf16.h — C ABI of the hand-written gfx950 bf16 residual tower (libaf_tower.so) used by
+ * BASELINE configs[4] (11x11, 8 residual blocks of the reference's block type at
+ * constant width 128, bf16, performance-only).  One block is genData/network.py:52-56:
+ *     r = conv1x1(h) + b_res ;  g = ELU(conv3x3(h) + b1) ;  h' = ELU(r + conv3x3(g) + b2)
+ * evaluated as two launches of one kernel (the projection is 8 extra k-steps of the second one) on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation, activations stored in bf16 like the PyTorch-ROCm bf16
+ * evaluator it replaces (alphafive_amd/network_deep.py).
+ *
+ * Activation layout ("C8"): bf16 [batch][width/8][PIX][8], PIX = (S+2)*S rounded up to 16 (144 at S = 11): rows
+ * are stored back to back with one zero row above and below the board, pixel (y, x) at unit S*(y+1) + x (a unit =
+ * the 8 channels of one pixel = 16 bytes).  The kernels never write the two zero rows; the missing left / right
+ * neighbours of a row's first / last pixel are handled inside the kernel.  The caller owns the two buffers.
+ *
+ * Plain pointers, int return codes (0 ok, <0 error), no exceptions; one handle per GPU.
+ */
+#ifndef AF_TOWER_BF16_H
+#define AF_TOWER_BF16_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct af_tower af_tower;
+
+#define AF_TOWER_OK 0
+#define AF_TOWER_ERR_ARG   (-1)
+#define AF_TOWER_ERR_HIP   (-2)
+#define AF_TOWER_ERR_STATE (-3)   /* forward before every block was set */
+
+/* board_size must be 11 and width 128 in this build (4 waves x 32 output channels, 4 pixel tiles). */
+int af_tower_create(int32_t board_size, int32_t width, int32_t blocks, int32_t device, af_tower** out);
+void af_tower_destroy(af_tower* t);
+
+/* Weights of block `b` (host pointers, fp32, PyTorch OIHW): c1_w/c2_w [W][W][3][3], res_w [W][W][1][1], biases [W].
+ * Values are rounded to bf16 (round-to-nearest-even) when packed. */
+int af_tower_set_block(af_tower* t, int32_t b, const float* c1_w, const float* c1_b, const float* c2_w, const float* c2_b,
+                       const float* res_w, const float* res_b);
+
+int32_t af_tower_pix(const af_tower* t);           /* PIX of the C8 layout */
+int64_t af_tower_plane_elems(const af_tower* t);   /* bf16 elements per position = width * PIX */
+
+/* Runs all blocks in place on x_dev (C8 bf16, zero borders); g_dev is scratch of the same size whose
+ * borders must be zero as well.  Asynchronous on `stream` (hipStream_t; NULL = default stream). */
+int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_t batch);
+
+/* A/B knobs (process-global): key 0 = B-fragment ring depth (8, 12, 16), key 1 = persistent workgroups (0 = one per CU). */
+int af_tower_tune(int32_t key, int32_t value);
+
+int64_t af_tower_flops_per_position(const af_tower* t);   /* 2*MAC of the tower, direct convolution */
+const char* af_tower_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -71,3 +71,18 @@ def test_product_fails_loudly_without_a_gpu(lib):
     from alphafive_amd.player import Player
     with pytest.raises(Exception):
         Player(make_cfg(), training=True, pv_fn=lambda x: None)
+
+
+@pytest.mark.parametrize("header, libname, prefix, least", [("af_net.h", "libaf_net.so", "af_net_", 8),
+                                                             ("af_tower_bf16.h", "libaf_tower.so", "af_tower_", 9)])
+def test_net_libraries_export_every_declared_symbol(lib, header, libname, prefix, least):
+    """include/af_net.h (fp32 net) and include/af_tower_bf16.h (bf16 residual tower of BASELINE configs[4])."""
+    hdr = open(os.path.join(REPO, "include", header)).read()
+    names = set(re.findall(r"\b(" + prefix + r"[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= least
+    nl = ctypes.CDLL(os.path.join(REPO, "alphafive_amd", "_lib", libname))
+    for n in names:
+        assert hasattr(nl, n), f"{n} declared in {header} but not exported"
+    fn = getattr(nl, prefix + "strerror")
+    fn.restype = ctypes.c_char_p
+    assert fn(-1) == b"bad argument"

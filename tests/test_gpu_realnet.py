@@ -101,17 +101,74 @@ def test_selfplay_engine_with_real_net_produces_valid_episodes():
     sp.close()
 
 
-def test_deep_bf16_evaluator_plugs_into_the_engine():
-    """BASELINE configs[4] shape: an 8-block bf16 net behind the same evaluator seam (performance-only config)."""
+def _rand_planes(B, S, seed):
+    rng = np.random.RandomState(seed)
+    x = np.zeros((B, 3, S, S), np.float32)
+    for b in range(B):
+        n = rng.randint(0, S * S - 1)
+        cells = rng.permutation(S * S)[:n + 1]
+        x[b, 0].reshape(-1)[cells[0:n:2]] = 1
+        x[b, 1].reshape(-1)[cells[1:n:2]] = 1
+        x[b, 2].reshape(-1)[cells[n]] = 1
+    return x
+
+
+def test_deep_bf16_tower_kernel_matches_fp32_reference():
+    """af_tower_forward (hand-written bf16 MFMA tower, BASELINE configs[4]) against an fp32 PyTorch evaluation of the
+    same bf16 weights with the activations rounded to bf16 at the same points (after each ELU).  Bar: the kernel's error
+    must not exceed the error of the all-PyTorch bf16 path it replaces (bf16 keeps 8 mantissa bits; no bit parity)."""
+    import torch
+    import torch.nn.functional as F
+    from alphafive_amd.network_deep import DeepResNet
+    B = 300                                          # more than one pass of the 256 persistent workgroups, ragged tail
+    net = DeepResNet(11, blocks=3, width=128, device="cuda", seed=3)
+    g = torch.Generator().manual_seed(5)
+    for blk in net.tower:                            # non-zero biases
+        for k in ("res", "c1", "c2"):
+            blk[k] = (blk[k][0], (torch.randn(128, generator=g) * 0.1).to("cuda", torch.bfloat16))
+    pv = net.select_backend("hip", B)
+    tw = net._tower
+    h0 = (torch.randn((B, 128, 11, 11), generator=g) * 0.5).to("cuda", torch.bfloat16)
+    ref = h0.float()
+    for blk in net.tower:
+        w = {k: (blk[k][0].float(), blk[k][1].float()) for k in blk}
+        mid = F.elu(F.conv2d(ref, *w["c1"], padding=1)).bfloat16().float()
+        ref = F.elu(F.conv2d(ref, *w["res"]) + F.conv2d(mid, *w["c2"], padding=1)).bfloat16().float()
+    tw.load_nchw(h0)
+    tw.forward(B)
+    out = tw.store_nchw(B).float()
+    torch_bf16 = net.tower_reference(h0).float()
+    err_hip, err_torch = (out - ref).abs(), (torch_bf16 - ref).abs()
+    assert torch.isfinite(out).all()
+    assert err_hip.mean().item() <= 1.1 * err_torch.mean().item() + 1e-4
+    assert err_hip.max().item() <= 2.0 * err_torch.max().item() + 0.02
+    S = 11                                           # the zero rows above / below the board are never written
+    for buf in (tw.x, tw.g):
+        assert float(buf[:, :, :S].float().abs().sum()) == 0.0 and float(buf[:, :, S + S * S:].float().abs().sum()) == 0.0
+    tw.load_nchw(h0)                                 # a second pass reproduces the result bit for bit
+    tw.forward(B)
+    assert torch.equal(tw.store_nchw(B).float(), out)
+    x = torch.from_numpy(_rand_planes(B, 11, seed=2)).cuda()     # end to end through the evaluator seam
+    p, v = pv(x)
+    p2, v2 = net.eval_device(x)
+    assert p.shape == (B, 121) and torch.allclose(p.sum(1), torch.ones(B, device="cuda"), atol=1e-3)
+    assert (p - p2).abs().max().item() < 0.05 and (v - v2).abs().max().item() < 0.1
+
+
+@pytest.mark.parametrize("backend", ["hip", "torch"])
+def test_deep_bf16_evaluator_plugs_into_the_engine(backend):
+    """BASELINE configs[4] shape: the 8-block width-128 bf16 net (hand-written tower, or all PyTorch ops) behind the
+    same evaluator seam as the fp32 net (performance-only config)."""
     import torch
     from alphafive_amd.engine import SelfPlayEngine
     from alphafive_amd.network_deep import DeepResNet
     net = DeepResNet(11, blocks=8, width=128, device="cuda")
+    pv = net.select_backend(backend, 512)
     cfg = make_cfg(simulation_per_step=30, upper_simulation_per_step=40)
-    sp = SelfPlayEngine(cfg, 512, net.eval_device, device=0, seed=2)
+    sp = SelfPlayEngine(cfg, 512, pv, device=0, seed=2)
     sp.run_ticks(40)
     sp.check()
-    p, v = net.eval_device(sp.planes)
+    p, v = pv(sp.planes)
     assert p.dtype == torch.float32 and p.shape == (512, 121) and torch.isfinite(p).all() and torch.isfinite(v).all()
     assert (p.sum(1) - 1).abs().max().item() < 1e-3 and v.abs().max().item() <= 1.0
     ct = sp.counters()
