@@ -69,11 +69,13 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem + kLds0;
 
+    auto stage_round = [&](const char* src, int pos, uint32_t off, int r) {   // 4 KB piece r of a position's plane -> LDS
+        glds16(src + (size_t)pos * kPlaneB + threadIdx.x * 16u + r * 4096,
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + off + wv * 1024u + r * 4096u)));
+    };
     auto stage = [&](const char* src, int pos, uint32_t off) {          // one position's plane -> LDS at byte offset off
-        const char* s = src + (size_t)pos * kPlaneB + threadIdx.x * 16u;
-        const uint32_t d = lds0 + off + wv * 1024u;
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) glds16(s + r * 4096, (uint32_t)__builtin_amdgcn_readfirstlane((int)(d + r * 4096u)));
+        for (int r = 0; r < kRounds; ++r) stage_round(src, pos, off, r);
     };
     int pos = blockIdx.x;
     if (pos >= A.batch) return;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
     }
     float bias_r[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias_r[r] = A.bias[32 * wv + 8 * (r >> 2) + 4 * kg + (r & 3)];
+    for (int r = 0; r < 16; ++r) bias_r[r] = A.bias[32 * wv + 16 * kg + r];   // MFMA rows are permuted at pack time: see pack_tower
 
     // the lane's pixel in each of the 4 pixel tiles: LDS byte base of tap (0,0) (one row up, one pixel left).  Rows are
     // stored back to back (no pad columns: consecutive lanes read consecutive 16-byte units, which is what keeps
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
         const int x = nc % kS;
         edgeL[j] = x == 0; edgeR[j] = x == kS - 1;
         lb[j] = kLds0 + (uint32_t)(kg * kPIX + nc + kS - (kS + 1)) * 16u;
-        ob[j] = (uint32_t)(nc + kS) * 16u + (uint32_t)kg * 8u;          // output unit of the pixel + this lane's k half
+        ob[j] = (uint32_t)(nc + kS) * 16u;                              // output unit of the pixel
     }
     // Pin the weight / bias loads' completion HERE: hipcc otherwise sinks its counted vmcnt waits to the first use of
     // each fragment inside the position loop, where they would also wait for the (to hipcc invisible) LDS-DMA of the
@@ -123,7 +125,6 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
         const uint32_t gcur = (it & 1) ? kPlaneB : 0u, gnxt = kPlaneB - gcur;
         const int nxt = pos + (int)gridDim.x;
         const bool more = nxt < A.batch && !(A.abl & 1);
-        if (more) stage(A.in, nxt, gnxt);
         f32x16 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -159,25 +160,30 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
             if (i + DEPTH < NM && !(A.abl & 8)) ring[i % DEPTH] = rd(i + DEPTH);   // abl bit 3 (profiling): no LDS reads
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            // the next position's planes are requested one 4 KB piece every 16 MFMAs (an LDS-DMA costs ~5 issue slots:
+            // in one burst they would stall the matrix pipe for the whole burst)
+            if (i % 16 == 0 && i / 16 < kRounds && more) stage_round(A.in, nxt, gnxt, i / 16);
+            if (PROJ && i >= NPJ && i % 16 == 8 && (i - NPJ) / 16 < kRounds && more) stage_round(A.in2, nxt, 2u * kPlaneB, (i - NPJ) / 16);
             if (PROJ && i == NPJ - 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();                    // every wave is done with the projection plane
-                if (more) stage(A.in2, nxt, 2u * kPlaneB);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the next position's planes have landed ...
         __builtin_amdgcn_s_barrier();                                   // ... for every wave, and all are done with this one
-        // epilogue: bias, ELU, bf16, store (cout block = 4*wave + r/4; 4 consecutive couts per lane = 8 bytes)
+        // epilogue: bias, ELU, bf16, store.  The weight rows are packed so that a lane's 16 accumulator rows are the 16
+        // consecutive couts 32*wave + 16*kg + r: two whole 8-channel units = two 16-byte stores per pixel tile, and the
+        // 32 lanes of a k half cover 512 contiguous bytes.
         char* const o = A.out + (size_t)pos * kPlaneB;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bf16x4 v;
+            for (int hf = 0; hf < 2; ++hf) {
+                bf16x8 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (__bf16)elu1(acc[j][4 * q + e] + bias_r[4 * q + e]);
-                if (ok[j] && !(A.abl & 2)) *reinterpret_cast<bf16x4*>(o + (uint32_t)((4 * wv + q) * kPIX) * 16u + ob[j]) = v;
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)elu1(acc[j][8 * hf + e] + bias_r[8 * hf + e]);
+                if (ok[j] && !(A.abl & 2)) *reinterpret_cast<bf16x8*>(o + (uint32_t)((4 * wv + 2 * kg + hf) * kPIX) * 16u + ob[j]) = v;
             }
     }
 }
@@ -198,7 +204,7 @@ static uint16_t bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
-// A fragments: [wave][s][lane][e] = W[cout = 32*wave + (lane&31)][cin = 16*cc + 8*(lane>>5) + e][tap t], s = 8*t + cc;
+// A fragments: [wave][s][lane][e] = W[cout = 32*wave + perm(lane&31)][cin = 16*cc + 8*(lane>>5) + e][tap t], s = 8*t + cc;
 // s = 72 + cc: the 1x1 projection.
 static std::vector<uint16_t> pack_tower(const float* w3, const float* w1x1) {
     const int NS = w1x1 ? 80 : 72;
@@ -207,7 +213,8 @@ static std::vector<uint16_t> pack_tower(const float* w3, const float* w1x1) {
         for (int s = 0; s < NS; ++s)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int co = 32 * wv + (lane & 31);
+                    const int m = lane & 31;                                    // MFMA row -> cout: lane half kg = (m>>2)&1 ends up holding
+                    const int co = 32 * wv + 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3);   // 16 consecutive couts in its 16 C rows
                     const int cc = s < 72 ? s % 8 : s - 72;
                     const int ci = 16 * cc + 8 * (lane >> 5) + e;
                     const float v = s < 72 ? w3[((size_t)co * 128 + ci) * 9 + s / 8] : w1x1[(size_t)co * 128 + ci];
