@@ -188,12 +188,153 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// af_tower_stem: the 5x5 stem (3 -> 128, SAME) + bias + ELU, planes fp32 [B][3][11][11] -> C8 bf16, on the same MFMA.
+// K = 3 planes x 5 rows x (5 taps padded to 8) = 15 groups of 8 = 8 k-steps; a B fragment (pixel n, group (cin, ky))
+// is the 8-wide input window starting at column x-2 of row y+ky-2, pre-expanded into LDS once per position as
+// 3 x 15 x 11 entries of 8 bf16 ("im2row"), so it is one aligned ds_read_b128.  Weights (8 A fragments) stay in
+// registers; workgroups are persistent over positions.
+struct StemArgs {
+    const float* planes;
+    const uint4* w;      // [4 waves][8][64] A fragments
+    const float* bias;   // [128]
+    char* out;           // C8 bf16
+    int batch;
+};
+
+__global__ __launch_bounds__(256) void af_tower_stem_kernel(StemArgs A) {
+    __shared__ __attribute__((aligned(16))) uint4 ent[3 * 15 * kS + 1];      // entry (cin, yy, x) = window x-2..x+5 of row yy-2
+    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    bf16x8 W[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const uint4 v = A.w[((size_t)wv * 8 + s) * 64 + lane];
+        __builtin_memcpy(&W[s], &v, 16);
+    }
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = A.bias[32 * wv + 16 * kg + r];
+    uint32_t lb[4], ob[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = 32 * j + nn;
+        ok[j] = n < kNPIX;
+        const int nc = ok[j] ? n : 0;
+        lb[j] = (uint32_t)nc;                                            // entry index of (cin 0, yy = y, x)
+        ob[j] = (uint32_t)(nc + kS) * 16u;
+    }
+    for (int pos = blockIdx.x; pos < A.batch; pos += gridDim.x) {
+        const float* pl = A.planes + (size_t)pos * 3 * kNPIX;
+        __syncthreads();                                                 // the previous position's reads are done
+        for (int en = threadIdx.x; en < 3 * 15 * kS; en += 256) {
+            const int cin = en / (15 * kS), rem = en - cin * 15 * kS, yy = rem / kS, x = rem - yy * kS;
+            const int y = yy - 2;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (y >= 0 && y < kS) {
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    const int xx = x - 2 + e;
+                    if (xx >= 0 && xx < kS) v[e] = (__bf16)pl[cin * kNPIX + y * kS + xx];
+                }
+            }
+            __builtin_memcpy(&ent[en], &v, 16);
+        }
+        __syncthreads();
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            // group g = 2s + kg -> (cin, ky); g = 15 is the zero pad of K (its weights are zero: any entry will do)
+            const int ga = 2 * s, gb = 2 * s + 1 < 15 ? 2 * s + 1 : 0;
+            const uint32_t offa = (uint32_t)((ga / 5) * 15 + ga % 5) * kS, offb = (uint32_t)((gb / 5) * 15 + gb % 5) * kS;
+            const uint32_t off = kg ? offb : offa;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8 b;
+                __builtin_memcpy(&b, &ent[lb[j] + off], 16);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s], b, acc[j], 0, 0, 0);
+            }
+        }
+        char* const o = A.out + (size_t)pos * kPlaneB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)elu1(acc[j][8 * hf + e] + bias_r[8 * hf + e]);
+                if (ok[j]) *reinterpret_cast<bf16x8*>(o + (uint32_t)((4 * wv + 2 * kg + hf) * kPIX) * 16u + ob[j]) = v;
+            }
+    }
+}
+
+// af_tower_heads_kernel: the two heads' 1x1 convolutions (128 -> 4 value, 128 -> 16 policy) + bias + ELU straight from the
+// C8 tower output into the flattened NCHW rows the dense layers take: vin [B][4*121], pin [B][16*121] (bf16).
+// 0.3 MMAC per position against 36 KB of input: HBM-bound, plain VALU (thread = pixel x half of the 20 couts, the
+// weights broadcast from LDS).
+struct HeadsArgs {
+    const char* x;       // C8 bf16
+    const float* w;      // [20][128] fp32 (bf16-rounded values): rows 0-3 value conv, 4-19 policy conv
+    const float* b;      // [20]
+    __bf16* vin;         // [B][484]
+    __bf16* pin;         // [B][1936]
+    int batch;
+};
+
+__global__ __launch_bounds__(256) void af_tower_heads_kernel(HeadsArgs A) {
+    __shared__ __attribute__((aligned(16))) float wl[20 * 128];
+    __shared__ float bl[20];
+    for (int i = threadIdx.x; i < 20 * 128; i += 256) wl[i] = A.w[i];
+    if (threadIdx.x < 20) bl[threadIdx.x] = A.b[threadIdx.x];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= 2 * kNPIX) return;
+    const int grp = t / kNPIX, p = t - grp * kNPIX;
+    for (int pos = blockIdx.x; pos < A.batch; pos += gridDim.x) {
+        const char* xp = A.x + (size_t)pos * kPlaneB + (uint32_t)(p + kS) * 16u;
+        float acc[10];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) acc[c] = bl[10 * grp + c];
+#pragma unroll 4
+        for (int cb = 0; cb < 16; ++cb) {
+            bf16x8 v;
+            const uint4 raw = *reinterpret_cast<const uint4*>(xp + (size_t)cb * kPIX * 16);
+            __builtin_memcpy(&v, &raw, 16);
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+#pragma unroll
+            for (int c = 0; c < 10; ++c) {
+                const float4 w0 = *reinterpret_cast<const float4*>(&wl[(10 * grp + c) * 128 + cb * 8]);
+                const float4 w1 = *reinterpret_cast<const float4*>(&wl[(10 * grp + c) * 128 + cb * 8 + 4]);
+                acc[c] += f[0] * w0.x + f[1] * w0.y + f[2] * w0.z + f[3] * w0.w + f[4] * w1.x + f[5] * w1.y + f[6] * w1.z + f[7] * w1.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            const int co = 10 * grp + c;
+            const __bf16 y = (__bf16)elu1(acc[c]);
+            if (co < 4) A.vin[(size_t)pos * (4 * kNPIX) + co * kNPIX + p] = y;
+            else A.pin[(size_t)pos * (16 * kNPIX) + (co - 4) * kNPIX + p] = y;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host ------------------------------------------------------------------
 struct af_tower {
     int S = 0, width = 0, blocks = 0, device = 0;
     std::vector<uint4*> w1, w2;
     std::vector<float*> b1, b2;
     std::vector<char> set;
+    uint4* stem_w = nullptr;
+    float* stem_b = nullptr;
+    float* heads_w = nullptr;
+    float* heads_b = nullptr;
 };
 
 static uint16_t bf16_rne(float f) {
@@ -277,6 +418,10 @@ void af_tower_destroy(af_tower* t) {
     for (auto p : t->w2) if (p) (void)hipFree(p);
     for (auto p : t->b1) if (p) (void)hipFree(p);
     for (auto p : t->b2) if (p) (void)hipFree(p);
+    if (t->stem_w) (void)hipFree(t->stem_w);
+    if (t->stem_b) (void)hipFree(t->stem_b);
+    if (t->heads_w) (void)hipFree(t->heads_w);
+    if (t->heads_b) (void)hipFree(t->heads_b);
     delete t;
 }
 
@@ -293,6 +438,67 @@ int af_tower_set_block(af_tower* t, int32_t b, const float* c1_w, const float* c
     if (!rc) rc = upload(&t->b2[b], bb.data(), 128 * 4);
     if (!rc) t->set[b] = 1;
     return rc;
+}
+
+static float bf16_round(float f) {
+    const uint32_t u = (uint32_t)bf16_rne(f) << 16;
+    float r;
+    memcpy(&r, &u, 4);
+    return r;
+}
+
+int af_tower_set_stem(af_tower* t, const float* w, const float* b) {
+    if (!t || !w || !b) return AF_TOWER_ERR_ARG;
+    TW_HIP_OK(hipSetDevice(t->device));
+    std::vector<uint16_t> pk((size_t)4 * 8 * 64 * 8, 0);                 // [wave][s][lane][e]
+    for (int wv = 0; wv < 4; ++wv)
+        for (int s = 0; s < 8; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 31, g = 2 * s + (lane >> 5);
+                const int co = 32 * wv + 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3);
+                if (g >= 15) continue;
+                for (int e = 0; e < 5; ++e)                               // w OIHW [128][3][5][5]
+                    pk[(((size_t)wv * 8 + s) * 64 + lane) * 8 + e] = bf16_rne(w[(((size_t)co * 3 + g / 5) * 5 + g % 5) * 5 + e]);
+            }
+    int rc = upload(&t->stem_w, pk.data(), pk.size() * 2);
+    if (!rc) rc = upload(&t->stem_b, b, 128 * 4);
+    return rc;
+}
+
+int af_tower_set_heads(af_tower* t, const float* vconv_w, const float* vconv_b, const float* pconv_w, const float* pconv_b) {
+    if (!t || !vconv_w || !vconv_b || !pconv_w || !pconv_b) return AF_TOWER_ERR_ARG;
+    TW_HIP_OK(hipSetDevice(t->device));
+    std::vector<float> w(20 * 128), b(20);
+    for (int c = 0; c < 20; ++c) {
+        b[c] = c < 4 ? vconv_b[c] : pconv_b[c - 4];
+        for (int k = 0; k < 128; ++k) w[c * 128 + k] = bf16_round(c < 4 ? vconv_w[c * 128 + k] : pconv_w[(c - 4) * 128 + k]);
+    }
+    int rc = upload(&t->heads_w, w.data(), w.size() * 4);
+    if (!rc) rc = upload(&t->heads_b, b.data(), b.size() * 4);
+    return rc;
+}
+
+int af_tower_stem(af_tower* t, void* stream, const float* planes_dev, void* x_dev, int32_t batch) {
+    if (!t || !planes_dev || !x_dev || batch < 1) return AF_TOWER_ERR_ARG;
+    if (!t->stem_w) return AF_TOWER_ERR_STATE;
+    StemArgs a;
+    a.planes = planes_dev; a.w = t->stem_w; a.bias = t->stem_b; a.out = static_cast<char*>(x_dev); a.batch = batch;
+    const int grid = batch < 1024 ? batch : 1024;
+    hipLaunchKernelGGL(af_tower_stem_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    TW_HIP_OK(hipGetLastError());
+    return AF_TOWER_OK;
+}
+
+int af_tower_heads(af_tower* t, void* stream, const void* x_dev, void* vin_dev, void* pin_dev, int32_t batch) {
+    if (!t || !x_dev || !vin_dev || !pin_dev || batch < 1) return AF_TOWER_ERR_ARG;
+    if (!t->heads_w) return AF_TOWER_ERR_STATE;
+    HeadsArgs a;
+    a.x = static_cast<const char*>(x_dev); a.w = t->heads_w; a.b = t->heads_b;
+    a.vin = static_cast<__bf16*>(vin_dev); a.pin = static_cast<__bf16*>(pin_dev); a.batch = batch;
+    const int grid = batch < 2048 ? batch : 2048;
+    hipLaunchKernelGGL(af_tower_heads_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    TW_HIP_OK(hipGetLastError());
+    return AF_TOWER_OK;
 }
 
 int32_t af_tower_pix(const af_tower*) { return kPIX; }

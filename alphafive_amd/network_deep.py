@@ -1,8 +1,9 @@
 """BASELINE configs[4]: a deeper policy/value net — N residual blocks of the reference's block type
 (network.py:52-56: 1x1 projection || 3x3+ELU -> 3x3, add, ELU) at constant width, the reference's two heads,
 evaluated in bf16.  The residual tower (99 % of the FLOPs) runs on the hand-written MFMA kernel of
-csrc/af_tower_bf16.hip (`select_backend("hip")`, the bench default); the 5x5 stem and the two heads stay on
-PyTorch-ROCm ops, as does the all-torch reference path `eval_device`.  Performance-only configuration (no checkpoint exists for
+csrc/af_tower_bf16.hip (`select_backend("hip")`, the bench default), as do the 5x5 stem and the heads' 1x1
+convolutions; only the three small dense layers and the softmax stay on PyTorch-ROCm ops.  `eval_device` is the
+all-PyTorch reference path.  Performance-only configuration (no checkpoint exists for
 it, random init, no bit parity); it plugs into SelfPlayEngine through the same
 planes[G,3,S,S] -> (prob[G,C], value[G]) evaluator seam as the fp32 net.
 """
@@ -61,11 +62,26 @@ class DeepResNet(object):
         if name != "hip":
             raise ValueError(name)
         from . import tower_hip
-        self._tower = tower_hip.HipTower(self.tower, self.board_size, self.width, max_batch, self.device)
+        self._tower = tower_hip.HipTower(self.tower, self.board_size, self.width, max_batch, self.device,
+                                         stem=self.stem, vconv=self.vconv, pconv=self.pconv)
         return self.eval_hip
 
     @torch.no_grad()
     def eval_hip(self, x):
+        """af_tower_stem -> af_tower_forward -> af_tower_heads (the 1x1 convs), then the three small dense layers and
+        the softmax on PyTorch ops (0.3 MMAC per position of 604)."""
+        B, tw = x.shape[0], self._tower
+        tw.stem(x.contiguous())
+        tw.forward(B)
+        vin, pin = tw.heads(B)
+        v = F.elu(vin @ self.vfc1[0] + self.vfc1[1])
+        v = torch.tanh((v @ self.vfc2[0] + self.vfc2[1]).float() / 2).squeeze(1)
+        p = torch.softmax((pin @ self.pfc[0] + self.pfc[1]).float(), dim=1)
+        return p, v
+
+    @torch.no_grad()
+    def eval_hip_torch_ends(self, x):
+        """The hand-written tower between PyTorch stem and heads (A/B reference for the stem / heads kernels)."""
         B, tw = x.shape[0], self._tower
         tw.load_nchw(F.elu(F.conv2d(x.to(self.dtype), self.stem[0], self.stem[1], padding=2)))
         tw.forward(B)

@@ -26,6 +26,10 @@ def lib():
         L.af_tower_destroy.argtypes = [vp]
         L.af_tower_destroy.restype = None
         L.af_tower_set_block.argtypes = [vp, C.c_int32, fp, fp, fp, fp, fp, fp]
+        L.af_tower_set_stem.argtypes = [vp, fp, fp]
+        L.af_tower_set_heads.argtypes = [vp, fp, fp, fp, fp]
+        L.af_tower_stem.argtypes = [vp, vp, vp, vp, C.c_int32]
+        L.af_tower_heads.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
         L.af_tower_pix.argtypes = [vp]
         L.af_tower_plane_elems.argtypes = [vp]
         L.af_tower_plane_elems.restype = C.c_int64
@@ -51,7 +55,7 @@ def tune(key, value):
 class HipTower(object):
     """blocks = list of dicts with torch tensors res/c1/c2 = (weight OIHW, bias), as DeepResNet.tower holds them."""
 
-    def __init__(self, blocks, board_size, width, max_batch, device):
+    def __init__(self, blocks, board_size, width, max_batch, device, stem=None, vconv=None, pconv=None):
         self.S, self.width, self.max_batch, self.device = board_size, width, max_batch, torch.device(device)
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -64,6 +68,14 @@ class HipTower(object):
         for b, blk in enumerate(blocks):
             keep = [host(blk[k][i]) for k in ("c1", "c2", "res") for i in (0, 1)]
             _check(lib().af_tower_set_block(self._h, b, *[p for _, p in keep]), f"af_tower_set_block({b})")
+        if stem is not None:
+            (_, wp), (_, bp) = keep = [host(stem[0]), host(stem[1])]
+            _check(lib().af_tower_set_stem(self._h, wp, bp), "af_tower_set_stem")
+        if vconv is not None:
+            keep = [host(t) for t in (vconv[0], vconv[1], pconv[0], pconv[1])]
+            _check(lib().af_tower_set_heads(self._h, *[p for _, p in keep]), "af_tower_set_heads")
+        self.vin = torch.empty((max_batch, 4 * board_size ** 2), dtype=torch.bfloat16, device=self.device)
+        self.pin = torch.empty((max_batch, 16 * board_size ** 2), dtype=torch.bfloat16, device=self.device)
         self.pix = int(lib().af_tower_pix(self._h))
         self.flops_per_position = int(lib().af_tower_flops_per_position(self._h))
         # C8 activations [B][width/8][PIX][8]; zero borders are never written by the kernels
@@ -79,6 +91,20 @@ class HipTower(object):
 
     def store_nchw(self, B):
         return self._xin[:B].permute(0, 1, 4, 2, 3).reshape(B, self.width, self.S, self.S)
+
+    def stem(self, planes):
+        """planes fp32 [B,3,S,S] (contiguous) -> the C8 buffer (af_tower_stem_kernel)."""
+        B = planes.shape[0]
+        assert planes.is_contiguous() and planes.dtype == torch.float32 and B <= self.max_batch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().af_tower_stem(self._h, stream, planes.data_ptr(), self.x.data_ptr(), B), "af_tower_stem")
+
+    def heads(self, B):
+        """-> (vin bf16 [B, 4*S*S], pin bf16 [B, 16*S*S]) = ELU(1x1 conv) of the tower output, flattened NCHW."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().af_tower_heads(self._h, stream, self.x.data_ptr(), self.vin.data_ptr(), self.pin.data_ptr(), B),
+               "af_tower_heads")
+        return self.vin[:B], self.pin[:B]
 
     def forward(self, B):
         stream = torch.cuda.current_stream(self.device).cuda_stream

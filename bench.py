@@ -231,8 +231,8 @@ def main():
         if deep is not None:
             roof = ({"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
                      "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"} if args.net.endswith("torch") else
-                    {"backend": "hip (af_tower_bf16.hip: bf16 MFMA implicit-GEMM tower, weight-stationary, LDS-DMA staging) + torch stem/heads",
-                     "kernel": "deep net forward = torch stem + 16x af_tower_conv + torch heads (whole forward timed; the tower carries 99 % of the FLOPs)"})
+                    {"backend": "hip (af_tower_bf16.hip: bf16 MFMA stem + implicit-GEMM tower, weight-stationary, LDS-DMA staging + heads 1x1 convs; dense layers on torch)",
+                     "kernel": "deep net forward = af_tower_stem + 16x af_tower_conv + af_tower_heads + 3 dense layers (whole forward timed; af_tower_conv carries 99 % of the FLOPs)"})
         out = {
             "metric": "self-play moves/sec (%dx%d, %d sims/move)" % (cfg.board_size, cfg.board_size, args.sims), "value": total_plies / t, "unit": "moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps,

@@ -39,12 +39,23 @@ void af_tower_destroy(af_tower* t);
 int af_tower_set_block(af_tower* t, int32_t b, const float* c1_w, const float* c1_b, const float* c2_w, const float* c2_b,
                        const float* res_w, const float* res_b);
 
+/* Stem (network.py:63 shape at width 128): 5x5 conv 3 -> W, SAME, + bias + ELU.  w [W][3][5][5] OIHW, b [W]. */
+int af_tower_set_stem(af_tower* t, const float* w, const float* b);
+/* The heads' 1x1 convolutions (network.py:70,82): value [4][W] + [4], policy [16][W] + [16] (OIHW with 1x1 dropped). */
+int af_tower_set_heads(af_tower* t, const float* vconv_w, const float* vconv_b, const float* pconv_w, const float* pconv_b);
+
 int32_t af_tower_pix(const af_tower* t);           /* PIX of the C8 layout */
 int64_t af_tower_plane_elems(const af_tower* t);   /* bf16 elements per position = width * PIX */
 
 /* Runs all blocks in place on x_dev (C8 bf16, zero borders); g_dev is scratch of the same size whose
  * borders must be zero as well.  Asynchronous on `stream` (hipStream_t; NULL = default stream). */
 int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_t batch);
+
+/* planes_dev float32[batch][3][S][S] (utils.py:256 layout) -> x_dev (C8 bf16; its zero rows are left untouched). */
+int af_tower_stem(af_tower* t, void* stream, const float* planes_dev, void* x_dev, int32_t batch);
+/* x_dev (C8 bf16) -> ELU(1x1 conv + bias), flattened NCHW as the dense layers take it (network.py:71,83):
+ * vin_dev bf16 [batch][4*S*S], pin_dev bf16 [batch][16*S*S]. */
+int af_tower_heads(af_tower* t, void* stream, const void* x_dev, void* vin_dev, void* pin_dev, int32_t batch);
 
 /* A/B knobs (process-global): key 0 = B-fragment ring depth (8, 12, 16), key 1 = persistent workgroups (0 = one per CU). */
 int af_tower_tune(int32_t key, int32_t value);

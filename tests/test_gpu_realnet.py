@@ -148,8 +148,23 @@ def test_deep_bf16_tower_kernel_matches_fp32_reference():
     tw.load_nchw(h0)                                 # a second pass reproduces the result bit for bit
     tw.forward(B)
     assert torch.equal(tw.store_nchw(B).float(), out)
-    x = torch.from_numpy(_rand_planes(B, 11, seed=2)).cuda()     # end to end through the evaluator seam
-    p, v = pv(x)
+    x = torch.from_numpy(_rand_planes(B, 11, seed=2)).cuda()
+    # stem kernel and heads' 1x1-conv kernel vs fp32 PyTorch ops on the same (bf16-valued) weights and inputs
+    net.stem = (net.stem[0], (torch.randn(128, generator=g) * 0.1).to("cuda", torch.bfloat16))
+    net.vconv = (net.vconv[0], (torch.randn(4, generator=g) * 0.1).to("cuda", torch.bfloat16))
+    net.pconv = (net.pconv[0], (torch.randn(16, generator=g) * 0.1).to("cuda", torch.bfloat16))
+    pv = net.select_backend("hip", B)
+    tw = net._tower
+    tw.stem(x)
+    stem_ref = F.elu(F.conv2d(x, net.stem[0].float(), net.stem[1].float(), padding=2))
+    assert (tw.store_nchw(B).float() - stem_ref).abs().max().item() <= 2.0 ** -8 * stem_ref.abs().max().item() + 1e-6
+    vin, pin = tw.heads(B)
+    h = tw.store_nchw(B).float()
+    v_ref = F.elu(F.conv2d(h, net.vconv[0].float(), net.vconv[1].float())).reshape(B, -1)
+    p_ref = F.elu(F.conv2d(h, net.pconv[0].float(), net.pconv[1].float())).reshape(B, -1)
+    assert (vin.float() - v_ref).abs().max().item() <= 2.0 ** -8 * v_ref.abs().max().item() + 1e-6
+    assert (pin.float() - p_ref).abs().max().item() <= 2.0 ** -8 * p_ref.abs().max().item() + 1e-6
+    p, v = pv(x)                                                 # end to end through the evaluator seam
     p2, v2 = net.eval_device(x)
     assert p.shape == (B, 121) and torch.allclose(p.sum(1), torch.ones(B, device="cuda"), atol=1e-3)
     assert (p - p2).abs().max().item() < 0.05 and (v - v2).abs().max().item() < 0.1

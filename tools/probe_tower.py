@@ -27,9 +27,12 @@ r32 = ref32(h0[:n]); rt = net.tower_reference(h0[:n]).float()
 print("hip vs fp32-ref: max|d| %.4f  mean|d| %.6f  max|ref| %.3f" % ((out[:n]-r32).abs().max().item(), (out[:n]-r32).abs().mean().item(), r32.abs().max().item()))
 print("torch-bf16 vs fp32-ref: max|d| %.4f mean|d| %.6f" % ((rt-r32).abs().max().item(), (rt-r32).abs().mean().item()))
 print("borders still zero:", float(tw.x.float().abs().sum() - tw._xin.float().abs().sum()) == 0.0)
-p1, v1 = pv(x); p2, v2 = net.eval_device(x)
+p1, v1 = pv(x); p2, v2 = net.eval_device(x); p3, v3 = net.eval_hip_torch_ends(x)
+# stem / heads kernels vs torch ops on the same data
+tw.stem(x); xs = tw.store_nchw(B).float(); print("stem |d| %.4f (max %.3f)" % ((xs - h0.float()).abs().max().item(), h0.float().abs().max().item()))
+print("hip-full vs hip-with-torch-ends: policy |d| %.2e value |d| %.2e" % ((p1-p3).abs().max().item(), (v1-v3).abs().max().item()))
 print("policy |d| %.2e value |d| %.2e" % ((p1-p2).abs().max().item(), (v1-v2).abs().max().item()))
-for name, fn in (("tower hip", lambda: tw.forward(B)), ("tower torch", lambda: net.tower_reference(h0)), ("net hip", lambda: pv(x)), ("net torch", lambda: net.eval_device(x))):
+for name, fn in (("tower hip", lambda: tw.forward(B)), ("tower torch", lambda: net.tower_reference(h0)), ("net hip", lambda: pv(x)), ("net hip + torch ends", lambda: net.eval_hip_torch_ends(x)), ("stem hip", lambda: tw.stem(x)), ("heads hip", lambda: tw.heads(B)), ("net torch", lambda: net.eval_device(x))):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(10): fn()
