@@ -19,6 +19,7 @@ TARGETS = {
     "libaf_hip.so": (["csrc/af_engine.hip"], ["-ffp-contract=off"]),
     "libaf_net.so": (["csrc/af_net.hip"], []),
     "libaf_tower.so": (["csrc/af_tower_bf16.hip"], []),
+    "libaf_replay.so": (["csrc/af_replay.hip"], []),
 }
 
 

@@ -69,7 +69,10 @@ class Trainer(object):
 
     def step(self, boards, weights, values, policies, lr):
         """One optimiser step on a RandomStack.get_data batch (main.py:63-68). Returns the scalar metrics."""
-        to = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=self.device)  # noqa: E731
+        def to(a):      # numpy batches (utils.RandomStack) or device tensors (replay.DeviceRandomStack)
+            if torch.is_tensor(a):
+                return a.to(device=self.device, dtype=torch.float32)
+            return torch.as_tensor(np.asarray(a, np.float32), device=self.device)
         terms = loss_terms(self.params, to(boards), to(policies), to(values), to(weights))
         grads = torch.autograd.grad(terms["total"], list(self.params.values()))
         self.t += 1
@@ -79,7 +82,7 @@ class Trainer(object):
                 self.m[k].mul_(self.beta1).add_(g, alpha=1.0 - self.beta1)
                 self.v[k].mul_(self.beta2).addcmul_(g, g, value=1.0 - self.beta2)
                 p.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + self.eps))
-        return {k: float(v) for k, v in terms.items()}
+        return {k: float(v.detach()) for k, v in terms.items()}
 
     def variables(self):
         return {k: p.detach().cpu().numpy().copy() for k, p in self.params.items()}

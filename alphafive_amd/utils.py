@@ -161,13 +161,23 @@ class RandomStack(object):
         print("black: white = %d: %d in the memory" % (self.black_win, self.white_win))
 
     def isEmpty(self):
-        return len(self.data) == 0
+        return self._size() == 0
 
     def is_full(self):
-        return len(self.data) >= self.length
+        return self._size() >= self.length
+
+    # ---- storage hooks (alphafive_amd.replay.DeviceRandomStack keeps the positions in HBM instead) ----
+    def _size(self):
+        return len(self.data)
+
+    def _store(self, data):
+        self.data.extend(data)
+
+    def _drop_front(self, n):
+        del self.data[:n]
 
     def _append_episode(self, data, result):
-        self.data.extend(data)
+        self._store(data)
         self.data_len.append(len(data))
         self.result.append(result)
 
@@ -202,9 +212,9 @@ class RandomStack(object):
             if _random.random() < (self.black_win - self.white_win) / (self.white_win * 1.02):
                 self._append_episode(data, result)
                 self.white_win += 1
-        beyond = len(self.data) - self.length
+        beyond = self._size() - self.length
         if beyond > 0:
-            del self.data[:beyond]
+            self._drop_front(beyond)
             while beyond >= self.data_len[0]:           # whole episodes fall out of the front
                 beyond -= self.data_len.pop(0)
                 gone = self.result.pop(0)

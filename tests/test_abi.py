@@ -74,9 +74,10 @@ def test_product_fails_loudly_without_a_gpu(lib):
 
 
 @pytest.mark.parametrize("header, libname, prefix, least", [("af_net.h", "libaf_net.so", "af_net_", 8),
-                                                             ("af_tower_bf16.h", "libaf_tower.so", "af_tower_", 9)])
+                                                             ("af_tower_bf16.h", "libaf_tower.so", "af_tower_", 13),
+                                                             ("af_replay.h", "libaf_replay.so", "af_replay_", 7)])
 def test_net_libraries_export_every_declared_symbol(lib, header, libname, prefix, least):
-    """include/af_net.h (fp32 net) and include/af_tower_bf16.h (bf16 residual tower of BASELINE configs[4])."""
+    """include/af_net.h (fp32 net), af_tower_bf16.h (bf16 net of BASELINE configs[4]), af_replay.h (device replay buffer)."""
     hdr = open(os.path.join(REPO, "include", header)).read()
     names = set(re.findall(r"\b(" + prefix + r"[a-z_0-9]+)\s*\(", hdr))
     assert len(names) >= least

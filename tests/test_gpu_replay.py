@@ -1,0 +1,101 @@
+"""DeviceRandomStack (libaf_replay.so through the C ABI) vs the host RandomStack, which tests/test_host_utils.py pins
+against the reference's utils.RandomStack (utils.py:14-146): same seeds -> the same accept/duplicate/evict decisions
+and bit-identical get_data batches (boards, weights, values, policies)."""
+import random
+
+import numpy as np
+import pytest
+
+from alphafive_amd import utils
+
+pytestmark = pytest.mark.gpu
+
+
+def _episodes(S, n_ep, seed):
+    """Random legal-looking episodes in the replay record format (utils.py:127: state, p[S,S], la, v, w)."""
+    rng = np.random.RandomState(seed)
+    eps = []
+    for _ in range(n_ep):
+        T = int(rng.randint(9, min(40, S * S)))
+        board = np.zeros((S, S), np.int8)
+        rec, la = [], None
+        w = utils.construct_weights(T, 0.94)
+        for t in range(T):
+            p = rng.rand(S, S).astype(np.float32)
+            p /= p.sum()
+            rec.append((utils.board_to_state(board), p, la, float((-1.0) ** (T - t)), w[t]))
+            empt = np.argwhere(board == 0)
+            a = tuple(int(v) for v in empt[rng.randint(len(empt))])
+            board = utils.step(board, a)
+            la = a
+        result = utils.DRAW if rng.rand() < 0.1 else (utils.BLACK_WIN if T % 2 == 1 else utils.WHITE_WIN)
+        eps.append((rec, result))
+    return eps
+
+
+@pytest.mark.parametrize("S, length, n_ep, batch", [(11, 300, 40, 64), (5, 60, 25, 200), (15, 500, 12, 33)])
+def test_device_randomstack_matches_host_class(S, length, n_ep, batch, capsys):
+    import torch
+    from alphafive_amd.replay import DeviceRandomStack
+    eps = _episodes(S, n_ep, seed=S)
+    outs = []
+    for cls in (utils.RandomStack, DeviceRandomStack):
+        random.seed(7)
+        np.random.seed(7)
+        st = cls(S, length) if cls is utils.RandomStack else cls(S, length, device=0)
+        assert st.isEmpty()
+        log = []
+        for k, (rec, res) in enumerate(eps):
+            log.append(st.push(rec, res))
+            if k % 5 == 4:
+                log.append([np.asarray(a.cpu() if torch.is_tensor(a) else a) for a in st.get_data(batch)])
+        log.append((st.black_win, st.white_win, list(st.data_len), list(st.result), st._size(), st.is_full()))
+        outs.append(log)
+        if cls is DeviceRandomStack:
+            st.close()
+    capsys.readouterr()
+    host, dev = outs
+    assert len(host) == len(dev)
+    n_batches = 0
+    for a, b in zip(host, dev):
+        if isinstance(a, list):
+            n_batches += 1
+            for x, y in zip(a, b):
+                assert x.shape == y.shape and x.dtype == y.dtype == np.float32
+                assert np.array_equal(x, y)
+        else:
+            assert a == b
+    assert n_batches >= 2 and host[-1][4] <= length          # the eviction path ran
+
+
+def test_device_randomstack_errors_are_loud():
+    from alphafive_amd import replay
+    st = replay.DeviceRandomStack(5, 10, device=0, max_episode=3)
+    rec = [(utils.board_to_state(np.zeros((5, 5), np.int8)), np.full((5, 5), 0.04, np.float32), None, 1.0, np.float32(1.0))] * 17
+    with pytest.raises(replay.ReplayError):          # 17 positions into a ring of 10 + 2*3
+        st._store(rec)
+    with pytest.raises(replay.ReplayError):
+        st._drop_front(1)
+    with pytest.raises(NotImplementedError):
+        st.save()
+    st.close()
+
+
+def test_trainer_consumes_device_batches():
+    """train.Trainer.step takes DeviceRandomStack.get_data's tensors directly (no host round trip)."""
+    import torch
+    from alphafive_amd.network import ResNet
+    from alphafive_amd.replay import DeviceRandomStack
+    from alphafive_amd.train import Trainer
+    random.seed(1)
+    np.random.seed(1)
+    st = DeviceRandomStack(11, 400, device=0)
+    for rec, res in _episodes(11, 12, seed=3):
+        st.push(rec, res)
+    net = ResNet(11, device="cuda", seed=0)
+    tr = Trainer(net.variables, 11, device="cuda")
+    boards, weights, values, policies = st.get_data(32)
+    assert boards.is_cuda and boards.shape == (32, 3, 11, 11)
+    m = tr.step(boards, weights, values, policies, lr=1e-3)
+    assert np.isfinite(m["total"])
+    st.close()
