@@ -43,10 +43,12 @@ int af_net_finalize(af_net* n);
 int af_net_forward(af_net* n, void* stream, const float* planes_dev, int32_t batch, float* policy_dev, float* value_dev);
 
 /* Benchmark / A-B knobs (process-global):
- *   key 0: conv path — 1 Winograd (default), 2 Winograd with U shared through LDS, 0 direct implicit GEMM
+ *   key 0: conv path — 1 Winograd register ring (default), 2 Winograd with U shared through LDS, 3 Winograd with both
+ *          operands staged by LDS-DMA, 4 Winograd on a persistent grid, 0 direct implicit GEMM
  *   key 1: number of sub-batch side streams (default 1)      key 2: sub-batch size (0 = batch / streams)
  *   key 3: ablation variant of the Winograd kernel (profiling only; results are wrong by design)
- *   key 4: value branch on a side stream (default 1) */
+ *   key 4: value branch on a side stream (default 1)         key 5: MFMA policy head (default 1)
+ *   key 6: workgroups of the persistent variant (default 256) */
 int af_net_tune(int32_t key, int32_t value);
 
 /* FLOPs (2*MAC) of one position's forward pass, as executed (direct convolution). */
