@@ -47,7 +47,7 @@ def tree_bytes(ct, C):
             + (32 + 16 * C + 4) * ct["expands"] + R * ct["sims"])
 
 
-def cpu_baseline(cfg, weights, budget_s=20.0):
+def cpu_baseline(cfg, weights, budget_s=20.0, game_id=0):
     """The C oracle (oracle/af_oracle.c, "port") + torch-CPU fp32 net on ONE host core: the same
     config-2 search for one game, first plies until the time budget is spent."""
     import torch
@@ -57,7 +57,7 @@ def cpu_baseline(cfg, weights, budget_s=20.0):
     net = ResNet(cfg.board_size, device="cpu", seed=0)
     if weights:
         net.load_npz(weights)
-    pl = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=0, game_id=0, pv_fn=net.eval)
+    pl = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=0, game_id=game_id, pv_fn=net.eval)
     board = np.zeros((cfg.board_size, cfg.board_size), np.int8)
     state, last, plies = oracle.board_to_state(board), None, 0
     t0 = time.time()
@@ -70,14 +70,62 @@ def cpu_baseline(cfg, weights, budget_s=20.0):
     dt = time.time() - t0
     st = pl.stats()
     pl.close()
-    return {"value": plies / dt, "unit": "moves/s", "cores": 1, "kind": "port",
+    return {"value": plies / dt, "unit": "moves/s", "cores": 1, "kind": "port", "plies": plies, "dt": dt,
             "sample": f"1 game, first {plies} plies of config 2 (11x11, {cfg.simulation_per_step} sims/move, "
                       f"training mode), C oracle + torch-CPU fp32 net, 1 thread, {dt:.1f} s, "
                       f"{st['sims']} sims / {st['expands']} net evals"}
 
 
+def cpu_baseline_all_cores(cfg, weights, budget_s=10.0, max_workers=64):
+    """one game per host core, every worker the same 1-thread C oracle + torch-CPU net as
+    cpu_baseline(); aggregate moves/s = all plies / the slowest worker's time."""
+    import subprocess
+    n = max(1, min(os.cpu_count() or 1, max_workers))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", AF_CPU_WORKER="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget_s), "--sims", str(cfg.simulation_per_step),
+           "--upper", str(cfg.upper_simulation_per_step), "--board", str(cfg.board_size)]
+    procs = [subprocess.Popen(cmd + ["--seed", str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for i in range(n)]
+    res = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=budget_s * 6 + 120)
+            res.append(json.loads(out.decode().strip().splitlines()[-1]))
+        except Exception:
+            p.kill()
+    if not res:
+        return None
+    plies, dt = sum(r["plies"] for r in res), max(r["dt"] for r in res)
+    return {"value": plies / dt, "unit": "moves/s", "cores": len(res), "host_cores": os.cpu_count(),
+            "sample": f"{len(res)} processes x 1 game x 1 thread, first plies of config 2 for {budget_s:.0f} s each "
+                      f"({plies} plies in {dt:.1f} s)"}
+
+
+def _cpu_worker(args):
+    cfg = make_cfg(args.sims, args.upper, args.board)
+    weights = os.path.join(REPO, "tests", "golden", "alphaFive-6960.weights.npz")
+    r = cpu_baseline(cfg, weights if cfg.board_size == 11 else None, budget_s=args.cpu_worker, game_id=args.seed)
+    print(json.dumps({"plies": r["plies"], "dt": r["dt"]}), flush=True)
+
+
+def copy_bandwidth_gbs(dev, mib=1024, reps=10):
+    """Measured device copy bandwidth (read + write bytes / time): the achievable-HBM denominator SURVEY §8d asks for."""
+    import torch
+    a = torch.empty(mib << 18, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -91,6 +139,8 @@ def main():
     ap.add_argument("--net", default="auto", choices=["auto", "torch", "hip", "deep-bf16", "deep-bf16-torch"],
                     help="deep-bf16 = BASELINE configs[4]: 8-block width-128 net in bf16 (use with --games 8192)")
     args = ap.parse_args()
+    if args.cpu_worker > 0:
+        return _cpu_worker(args)
 
     import torch
     import torch.distributed as dist
@@ -233,6 +283,7 @@ def main():
                      "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"} if args.net.endswith("torch") else
                     {"backend": "hip (af_tower_bf16.hip: bf16 MFMA stem + implicit-GEMM tower, weight-stationary, LDS-DMA staging + heads 1x1 convs; dense layers on torch)",
                      "kernel": "deep net forward = af_tower_stem + 16x af_tower_conv + af_tower_heads + 3 dense layers (whole forward timed; af_tower_conv carries 99 % of the FLOPs)"})
+        copy_gbs = copy_bandwidth_gbs(dev)
         out = {
             "metric": "self-play moves/sec (%dx%d, %d sims/move)" % (cfg.board_size, cfg.board_size, args.sims), "value": total_plies / t, "unit": "moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps,
@@ -254,11 +305,13 @@ def main():
                          "flop_per_launch": G * flop_pos},
             "tree_roofline": {"kernel": "af_tick_kernel<%d>" % (2 if C <= 128 else 4), "bound": "hbm", "achieved": tree_gbs,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": traffic_tick,
-                              "ms_per_launch": tick_ms, "bytes_per_launch": tree_bytes(d, C) / n_ticks},
+                              "ms_per_launch": tick_ms, "bytes_per_launch": tree_bytes(d, C) / n_ticks,
+                              "peak_measured_copy": copy_gbs, "frac_of_measured_copy": tree_gbs / copy_gbs},
             "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, weights if cfg.board_size == 11 else None)
+            out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, weights if cfg.board_size == 11 else None)
         print(json.dumps(out), flush=True)
     sp.close()
     if world > 1:
