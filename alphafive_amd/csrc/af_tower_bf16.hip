@@ -12,8 +12,8 @@
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4: contiguous, no staging registers), double buffered:
 // position i+1 lands while position i multiplies.  In C8, a B fragment (32 pixels x 16 cin) is one
 // ds_read_b128 per lane at lane_base + compile-time offset (pixel units are 16 bytes, consecutive pixels are
-// consecutive units => conflict-free; a row's missing left/right neighbours are zeroed by lane masks), so the inner
-// loop is ds_read_b128 + MFMA (+ 4 v_cndmask on two taps out of three).
+// consecutive units => conflict-free; for a row's missing left/right neighbours the edge lanes read an all-zero LDS
+// region at the same bank offset instead), so the inner loop is ds_read_b128 + MFMA only.
 // Epilogue: bias, ELU, round to bf16, 8-byte stores that pair up (k halves) into contiguous 512-byte runs.
 //
 // Roofline: 2*128*128*9*121 = 35.7 MFLOP per position and convolution on 2.5 PFLOP/s dense bf16 MFMA;
@@ -60,6 +60,7 @@ constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;                    // 13 row
 constexpr uint32_t kPlaneB = 16u * kPIX * 16u;                          // 36,864 bytes per position
 constexpr int kRounds = kPlaneB / (256 * 16);                           // 9 LDS-DMA rounds of 256 lanes x 16 B
 constexpr uint32_t kLds0 = 256u;                                        // planes start here: unit -1 of a plane stays inside LDS
+constexpr uint32_t kZeroB = 33024u;                                     // all-zero LDS region the edge lanes read instead of a wrapped neighbour
 
 template <bool PROJ, int DEPTH>
 __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
@@ -79,6 +80,8 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
     };
     int pos = blockIdx.x;
     if (pos >= A.batch) return;
+    constexpr uint32_t kZoff = kLds0 + (PROJ ? 3u : 2u) * kPlaneB;      // the zero region follows the planes
+    for (uint32_t u = threadIdx.x; u < kZeroB / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
     stage(A.in, pos, 0u);
     if (PROJ) stage(A.in2, pos, 2u * kPlaneB);
 
@@ -98,8 +101,9 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
 
     // the lane's pixel in each of the 4 pixel tiles: LDS byte base of tap (0,0) (one row up, one pixel left).  Rows are
     // stored back to back (no pad columns: consecutive lanes read consecutive 16-byte units, which is what keeps
-    // ds_read_b128 conflict-free), so the left / right taps of the first / last pixel of a row are zeroed by lane masks.
-    uint32_t lb[4], ob[4];
+    // ds_read_b128 conflict-free); for the left / right taps of the first / last pixel of a row the lane reads zeros
+    // from a dedicated LDS region (a different base register, no per-read VALU).
+    uint32_t lb[4], ob[4], zb[4];
     bool ok[4], edgeL[4], edgeR[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -110,6 +114,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
         edgeL[j] = x == 0; edgeR[j] = x == kS - 1;
         lb[j] = kLds0 + (uint32_t)(kg * kPIX + nc + kS - (kS + 1)) * 16u;
         ob[j] = (uint32_t)(nc + kS) * 16u;                              // output unit of the pixel
+        zb[j] = kZoff + (lb[j] & 255u);                                 // same banks as the lane's own unit: stays conflict-free
     }
     // Pin the weight / bias loads' completion HERE: hipcc otherwise sinks its counted vmcnt waits to the first use of
     // each fragment inside the position loop, where they would also wait for the (to hipcc invisible) LDS-DMA of the
@@ -118,13 +123,20 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
     for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(W[s]));
 #pragma unroll
     for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bias_r[r]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // first planes landed, zero region written
     __builtin_amdgcn_s_barrier();
 
     for (int it = 0; pos < A.batch; pos += gridDim.x, ++it) {
         const uint32_t gcur = (it & 1) ? kPlaneB : 0u, gnxt = kPlaneB - gcur;
         const int nxt = pos + (int)gridDim.x;
         const bool more = nxt < A.batch && !(A.abl & 1);
+        uint32_t bC[4], bL[4], bR[4];                                   // read bases for the centre / left / right tap columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bC[j] = gcur + lb[j];
+            bL[j] = edgeL[j] ? zb[j] : bC[j];
+            bR[j] = edgeR[j] ? zb[j] : bC[j];
+        }
         f32x16 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -141,7 +153,8 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
                 return *reinterpret_cast<const bf16x8*>(smem + 2u * kPlaneB + lb[j] + (uint32_t)(2 * cc * kPIX + kS + 1) * 16u);
             }
             const int s_ = (i - NPJ) >> 2, t = s_ >> 3, cc = s_ & 7;
-            return *reinterpret_cast<const bf16x8*>(smem + gcur + lb[j] + (uint32_t)(2 * cc * kPIX + (t / 3) * kS + (t % 3)) * 16u);
+            const uint32_t base = t % 3 == 0 ? bL[j] : (t % 3 == 2 ? bR[j] : bC[j]);
+            return *reinterpret_cast<const bf16x8*>(smem + base + (uint32_t)(2 * cc * kPIX + (t / 3) * kS + (t % 3)) * 16u);
         };
         bf16x8 ring[DEPTH];
 #pragma unroll
@@ -149,14 +162,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
 #pragma clang loop unroll(full)
         for (int i = 0; i < NM; ++i) {
             const int ws = i < NPJ ? 72 + (i >> 2) : (i - NPJ) >> 2;
-            bf16x8 bfr = ring[i % DEPTH];
-            if (i >= NPJ) {
-                const int dx = (((i - NPJ) >> 2) >> 3) % 3;
-                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (dx == 0) bfr = edgeL[i & 3] ? zero : bfr;
-                if (dx == 2) bfr = edgeR[i & 3] ? zero : bfr;
-            }
-            acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[ws], bfr, acc[i & 3], 0, 0, 0);
+            acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[ws], ring[i % DEPTH], acc[i & 3], 0, 0, 0);
             if (i + DEPTH < NM && !(A.abl & 8)) ring[i % DEPTH] = rd(i + DEPTH);   // abl bit 3 (profiling): no LDS reads
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
@@ -521,14 +527,14 @@ int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_
         // ring depth per kernel: the deepest that hipcc allocates without scratch (a scratch reload's vmcnt(0) would
         // also wait for the LDS-DMA of the next position: measured 400 vs 230 us per launch)
         const int d1 = g_depth ? g_depth : 12, d2 = g_depth ? g_depth : 8;
-        if (d1 == 16) hipLaunchKernelGGL((af_tower_conv<false, 16>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB, st, a);
-        else if (d1 == 12) hipLaunchKernelGGL((af_tower_conv<false, 12>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB, st, a);
-        else hipLaunchKernelGGL((af_tower_conv<false, 8>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB, st, a);
+        if (d1 == 16) hipLaunchKernelGGL((af_tower_conv<false, 16>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);
+        else if (d1 == 12) hipLaunchKernelGGL((af_tower_conv<false, 12>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);
+        else hipLaunchKernelGGL((af_tower_conv<false, 8>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);
         a.in = static_cast<const char*>(g_dev); a.in2 = xin; a.w = t->w2[b]; a.bias = t->b2[b];
         a.out = static_cast<char*>(x_dev);
-        if (d2 == 16) hipLaunchKernelGGL((af_tower_conv<true, 16>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB, st, a);
-        else if (d2 == 12) hipLaunchKernelGGL((af_tower_conv<true, 12>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB, st, a);
-        else hipLaunchKernelGGL((af_tower_conv<true, 8>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB, st, a);
+        if (d2 == 16) hipLaunchKernelGGL((af_tower_conv<true, 16>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, a);
+        else if (d2 == 12) hipLaunchKernelGGL((af_tower_conv<true, 12>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, a);
+        else hipLaunchKernelGGL((af_tower_conv<true, 8>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, a);
     }
     TW_HIP_OK(hipGetLastError());
     return AF_TOWER_OK;
