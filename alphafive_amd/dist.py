@@ -2,8 +2,8 @@
 collective on the tick path).  The only exchanges are the ones SURVEY §8e lists:
 
   broadcast_weights   one broadcast of the 3 MB fp32 weight set from rank 0 (per weight update)
-  gather_episodes     finished episodes -> rank 0 (variable length: sizes all-gather, then
-                      point-to-point send/recv into rank-0 staging) — the device-side
+  gather_episodes     finished episodes -> rank 0 (variable length: sizes all-gather, then one
+                      padded all-gather; rank 0 keeps the result) — the device-side
                       replacement of main.py:51,94's multiprocessing.Queue hand-off
   all_reduce_sum      the moves counter for the metric
 
@@ -64,17 +64,19 @@ def gather_episodes(eps, world, rank, device, game_offset=None):
     sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([payload.numel()], dtype=torch.int64, device=device))
     sizes = [int(s.item()) for s in sizes]
-    if rank == 0:
-        out = list(eps)
-        bufs = [torch.empty(sizes[r], dtype=torch.int32, device=device) for r in range(1, world)]
-        reqs = [dist.irecv(bufs[r - 1], src=r) for r in range(1, world)]
-        for q in reqs:
-            q.wait()
-        for b in bufs:
-            out += unpack_episodes(b.cpu().numpy())
-        return out
-    dist.isend(payload, dst=0).wait()
-    return []
+    # one padded all-gather (the collective every backend has; RCCL point-to-point would open a communicator per
+    # rank pair on first use): <= a few MB per rank and step, off the tick path
+    width = max(sizes)
+    padded = torch.zeros(width, dtype=torch.int32, device=device)
+    padded[:payload.numel()] = payload
+    bufs = [torch.empty(width, dtype=torch.int32, device=device) for _ in range(world)]
+    dist.all_gather(bufs, padded)
+    if rank != 0:
+        return []
+    out = list(eps)
+    for r in range(1, world):
+        out += unpack_episodes(bufs[r][:sizes[r]].cpu().numpy())
+    return out
 
 
 def broadcast_weights(net, src=0):

@@ -76,11 +76,35 @@ def cpu_baseline(cfg, weights, budget_s=20.0, game_id=0):
                       f"{st['sims']} sims / {st['expands']} net evals"}
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                tok = f.read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    n = min(n, max(1, int(float(tok[0]) / float(tok[1]))))
+            else:
+                q = int(tok[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline_all_cores(cfg, weights, budget_s=10.0, max_workers=64):
     """one game per host core, every worker the same 1-thread C oracle + torch-CPU net as
     cpu_baseline(); aggregate moves/s = all plies / the slowest worker's time."""
     import subprocess
-    n = max(1, min(os.cpu_count() or 1, max_workers))
+    n = max(1, min(usable_cores(), max_workers))
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", AF_CPU_WORKER="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget_s), "--sims", str(cfg.simulation_per_step),
            "--upper", str(cfg.upper_simulation_per_step), "--board", str(cfg.board_size)]
@@ -95,7 +119,7 @@ def cpu_baseline_all_cores(cfg, weights, budget_s=10.0, max_workers=64):
     if not res:
         return None
     plies, dt = sum(r["plies"] for r in res), max(r["dt"] for r in res)
-    return {"value": plies / dt, "unit": "moves/s", "cores": len(res), "host_cores": os.cpu_count(),
+    return {"value": plies / dt, "unit": "moves/s", "cores": len(res), "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
             "sample": f"{len(res)} processes x 1 game x 1 thread, first plies of config 2 for {budget_s:.0f} s each "
                       f"({plies} plies in {dt:.1f} s)"}
 
