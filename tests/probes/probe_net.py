@@ -1,12 +1,12 @@
 """Scratch probe: HIP net vs torch net (numerics + time)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from alphafive_amd.network import ResNet
 from oracle import net_fp64
 S = int(os.environ.get("S", 11)); B = int(os.environ.get("B", 4096))
 net = ResNet(S, device="cuda", seed=1)
-if S == 11: net.load_npz(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/alphaFive-6960.weights.npz"))
+if S == 11: net.load_npz(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests/golden/alphaFive-6960.weights.npz"))
 rng = np.random.RandomState(0)
 x = np.zeros((B, 3, S, S), np.float32)
 for b in range(B):
