@@ -80,3 +80,48 @@ def test_config2_full_size_parity_invariants_and_sharding():
     for k in ("keys", "sum_n", "n"):
         assert (big_last[k] == shard_last[k]).all()
     assert (big_last["w"].view(np.uint32) == shard_last["w"].view(np.uint32)).all()
+
+
+def test_config4_full_size_15x15_invariants_oracle_and_sharding():
+    """BASELINE configs[3] shape: 4096 games on 15x15, 800 sims/move (cap 942), KW = 4 bitboard words per colour.
+    Forced root visits alone take 2 * 225 = 450 of the 800 simulations at the empty board."""
+    from alphafive_amd.engine import SelfPlayEngine
+    cfg = make_cfg(board_size=15, simulation_per_step=800, upper_simulation_per_step=942)
+    G, S = 4096, 15
+
+    def run(G_, first, ticks=830):
+        sp = SelfPlayEngine(cfg, G_, lambda x: pseudonet.pseudonet_torch(x, SALT, PEAK), device=0, seed=SEED,
+                            first_game_id=first)
+        sp.run_ticks(ticks)
+        sp.check()
+        ct = sp.counters()
+        dumps = {g: sp.engine.tree_dump(g) for g in (0, G_ - 1)}
+        sp.close()
+        return ct, dumps
+
+    ct, dumps = run(G, 0)
+    assert ct["plies"] == G                           # 830 ticks: every game committed exactly one move
+    assert ct["sims"] == ct["expands"] + ct["terminals"] and ct["episodes"] == 0
+    for g, d in dumps.items():
+        ahead = d["sum_n"] - d["n"].sum(1)
+        assert ((ahead == 0) | (ahead == 1)).all() and ahead.sum() <= 8
+        assert np.abs(d["p"].sum(1) - 1.0).max() < 1e-4 and np.isfinite(d["w"]).all()
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
+                                  pseudo_salt=SALT, pseudo_peak=PEAK)
+        state = oracle.board_to_state(np.zeros((S, S), np.int8))
+        orc.get_action(state, None)                   # the one committed move
+        od = orc.tree_dump()
+        omap = {od["keys"][i].tobytes(): i for i in range(len(od["sum_n"]))}
+        hits = 0
+        for i in range(len(d["sum_n"])):
+            j = omap.get(np.ascontiguousarray(d["keys"][i]).tobytes())
+            if j is None:
+                continue                              # created by the second move's simulations already under way
+            assert (d["p"][i].view(np.uint32) == od["p"][j].view(np.uint32)).all()
+            assert (d["n"][i] >= od["n"][j]).all()
+            hits += 1
+        assert hits > 300
+    ct_s, dumps_s = run(1024, 3072)                   # games 3072..4095 in their own engine
+    for k in ("keys", "sum_n", "n"):
+        assert (dumps[G - 1][k] == dumps_s[1023][k]).all()
+    assert (dumps[G - 1]["w"].view(np.uint32) == dumps_s[1023]["w"].view(np.uint32)).all()
