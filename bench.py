@@ -294,14 +294,14 @@ def main():
         # committed counter profile when this run is the profiled workload, else null
         traffic_net = traffic_tick = None
         traffic_src = None
-        tp = os.path.join(REPO, "profiles", "r1_08_pmc_hbm_traffic.json")
+        tp = os.path.join(REPO, "profiles", "r1_14_pmc_hbm_traffic.json")
         if os.path.exists(tp) and deep is None and roof["backend"].startswith("hip"):
             with open(tp) as f:
                 prof = json.load(f)
             if prof["workload"] == {"games": G, "board_size": cfg.board_size}:
                 traffic_net = prof["net_forward_bytes_per_launch"]["corrected"]
                 traffic_tick = prof["tick_kernel_bytes_per_launch"]["corrected"]
-                traffic_src = "profiles/r1_08_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                traffic_src = "profiles/r1_14_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         if deep is not None:
             roof = ({"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
                      "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"} if args.net.endswith("torch") else
