@@ -103,6 +103,8 @@ def test_player_run_and_reset_match_oracle():
     (6, 4, 60, 80, 64, 0),
     (7, 4, 40, 60, 48, 0),
     (6, 4, 60, 80, 16, 100),      # tight store: exercises the superset compaction every move
+    (11, 5, 500, 642, 16, 0),     # BASELINE configs[1] search settings: complete 11x11 episodes, 500 sims/move
+    (15, 5, 120, 160, 8, 0),      # 4-word bitboards (BASELINE configs[3] board), complete episodes
 ])
 def test_selfplay_episodes_match_oracle(S, goal, sims, upper, G, node_cap):
     import torch
@@ -113,7 +115,7 @@ def test_selfplay_episodes_match_oracle(S, goal, sims, upper, G, node_cap):
                         first_game_id=first, node_cap=node_cap)
     want = 2 * G
     got = {}
-    for _ in range(400):
+    for _ in range(400 if S < 11 else 1500):
         sp.run_ticks(64)
         sp.check()
         for raw in sp.pop_raw(cap=64):
