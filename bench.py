@@ -330,7 +330,8 @@ def main():
             "tree_roofline": {"kernel": "af_tick_kernel<%d>" % (2 if C <= 128 else 4), "bound": "hbm", "achieved": tree_gbs,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": traffic_tick,
                               "ms_per_launch": tick_ms, "bytes_per_launch": tree_bytes(d, C) / n_ticks,
-                              "peak_measured_copy": copy_gbs, "frac_of_measured_copy": tree_gbs / copy_gbs},
+                              "peak_measured_copy": copy_gbs, "frac_of_measured_copy": tree_gbs / copy_gbs,
+                              "note": "SURVEY 8d bound (HBM); PMC (profiles/r1_16) shows the kernel limited by per-game serial latency and fp64 VALU work of the noise generator"},
             "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms},
         }
         if not args.no_cpu_baseline:
