@@ -50,14 +50,19 @@ class HipNet(object):
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _check(lib().af_net_create(board_size, max_batch, idx, C.byref(self._h)), "af_net_create")
+        self.load(variables)
+        self.flops_per_position = int(lib().af_net_flops_per_position(self._h))
+        self.policy = torch.empty((max_batch, board_size * board_size), dtype=torch.float32, device=self.device)
+        self.value = torch.empty((max_batch,), dtype=torch.float32, device=self.device)
+
+    def load(self, variables):
+        """(Re)load a weight set: af_net_set_variable for every tensor, then af_net_finalize repacks and uploads."""
+        torch.cuda.synchronize(self.device)             # no forward may still be reading the old packed weights
         for name, arr in variables.items():
             a = np.ascontiguousarray(arr, np.float32)
             _check(lib().af_net_set_variable(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size),
                    f"af_net_set_variable({name})")
         _check(lib().af_net_finalize(self._h), "af_net_finalize")
-        self.flops_per_position = int(lib().af_net_flops_per_position(self._h))
-        self.policy = torch.empty((max_batch, board_size * board_size), dtype=torch.float32, device=self.device)
-        self.value = torch.empty((max_batch,), dtype=torch.float32, device=self.device)
 
     def bind_outputs(self, policy, value):
         """Write results straight into caller-owned device tensors (no copy on the tick path)."""
@@ -89,7 +94,7 @@ def make_eval(resnet):
     if resnet.device.type != "cuda" or not (3 <= resnet.board_size <= 15):
         return None
     lib()
-    state = {"net": None, "out": None}
+    state = {"net": None, "out": None, "version": None}
 
     def pv(planes):
         B = planes.shape[0]
@@ -97,8 +102,12 @@ def make_eval(resnet):
             if state["net"] is not None:
                 state["net"].close()
             state["net"] = HipNet(resnet.variables, resnet.board_size, B, resnet.device)
+            state["version"] = getattr(resnet, "version", None)
             if state["out"] is not None and state["out"][0].shape[0] >= B:
                 state["net"].bind_outputs(*state["out"])
+        elif state["version"] != getattr(resnet, "version", None):
+            state["net"].load(resnet.variables)          # set_variables / restore / load_npz since the last call (a weight update)
+            state["version"] = getattr(resnet, "version", None)
         return state["net"](planes)
 
     def bind_outputs(policy, value):

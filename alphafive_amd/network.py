@@ -97,6 +97,7 @@ class ResNet(object):
                 tv = tv.permute(3, 2, 0, 1).contiguous()          # HWIO -> OIHW
             t[k] = tv.to(self.device)
         self._t = t
+        self.version = getattr(self, "version", 0) + 1      # evaluators built from an older weight set reload (net_hip.make_eval)
 
     def restore(self, ckpt_path):
         """network.py:113-122: directory with a `checkpoint` file or a checkpoint prefix."""

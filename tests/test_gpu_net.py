@@ -101,3 +101,24 @@ def test_alternate_conv_paths_agree_with_fp64():
             assert np.abs(p[:32].cpu().numpy() - p64).max() < 1e-5, mode
     finally:
         net_hip.tune(0, 1)
+
+
+def test_hip_evaluator_follows_weight_updates():
+    """A weight update (set_variables / restore / load_npz — what train_loop and a checkpoint reload do) must reach the
+    hand-written kernels: the evaluator handed out by select_backend("hip") repacks and re-uploads on its next call."""
+    import torch
+    from alphafive_amd.network import ResNet, random_variables
+    net = ResNet(11, device="cuda", seed=1)
+    pv = net.select_backend("hip")
+    x = _positions(11, 40, seed=9)
+    xt = torch.from_numpy(x).cuda()
+    p1, v1 = (t.clone() for t in pv(xt))
+    net.set_variables(random_variables(11, seed=2))
+    p2, v2 = (t.clone() for t in pv(xt))
+    p64, v64 = net_fp64.forward(net.variables, x)
+    assert np.abs(p2.cpu().numpy() - p64).max() < 1e-5 and np.abs(v2.cpu().numpy() - v64).max() < 1e-5
+    assert (p2 - p1).abs().max().item() > 1e-4            # it really was a different weight set
+    net.load_npz(W)
+    p3, v3 = pv(xt)
+    p64, v64 = net_fp64.forward(net.variables, x)
+    assert np.abs(p3.cpu().numpy() - p64).max() < 1e-5 and np.abs(v3.cpu().numpy() - v64).max() < 1e-5

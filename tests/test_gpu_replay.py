@@ -99,3 +99,38 @@ def test_trainer_consumes_device_batches():
     m = tr.step(boards, weights, values, policies, lr=1e-3)
     assert np.isfinite(m["total"])
     st.close()
+
+
+def test_closed_loop_self_play_replay_train_on_device(capsys):
+    """train.train_loop (main.py:57-76) with every stage on the GPU: SelfPlayEngine -> DeviceRandomStack -> Trainer, the
+    engine's hand-written evaluator picking up each weight update."""
+    import types
+    import torch
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.network import ResNet
+    from alphafive_amd.replay import DeviceRandomStack
+    from alphafive_amd.train import Trainer, train_loop
+    from conftest import make_cfg
+    random.seed(3)
+    np.random.seed(3)
+    S = 6
+    cfg = make_cfg(board_size=S, goal=4, simulation_per_step=16, upper_simulation_per_step=24, batch_size=64)
+    cfg.get_lr = lambda step: 1e-3
+    cfg.ckpt_path = "/tmp/af_closed_loop_ckpt"
+    net = ResNet(S, device="cuda", seed=0)
+    before = {k: v.copy() for k, v in net.variables.items()}
+    sp = SelfPlayEngine(cfg, 64, net.select_backend("hip"), device=0, seed=1)
+    stack = DeviceRandomStack(S, 120, device=0)
+    tr = Trainer(net.variables, S, device="cuda")
+    logs = []
+    steps = train_loop(cfg, sp, net, stack, tr, steps=4, log=logs.append)
+    capsys.readouterr()
+    assert steps >= 4 and len(logs) >= 3 and all("xcross_loss" in s for s in logs)
+    assert stack.is_full() and stack._size() <= 120
+    assert any(np.abs(net.variables[k] - before[k]).max() > 0 for k in before)     # the weights moved ...
+    x = torch.zeros((2, 3, S, S), device="cuda")
+    p_hip, v_hip = sp.pv(x) if hasattr(sp, "pv") else net.select_backend("hip")(x)
+    p_t, v_t = net.eval_device(x)
+    assert (p_hip - p_t).abs().max().item() < 1e-5                                 # ... and the HIP evaluator has them
+    sp.close()
+    stack.close()
