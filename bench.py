@@ -334,7 +334,7 @@ def main():
                               "note": "SURVEY 8d bound (HBM); PMC (profiles/r1_16) shows the kernel limited by per-game serial latency and fp64 VALU work of the noise generator"},
             "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, weights if cfg.board_size == 11 else None)
             out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, weights if cfg.board_size == 11 else None)
         print(json.dumps(out), flush=True)
