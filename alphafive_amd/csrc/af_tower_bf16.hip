@@ -14,7 +14,8 @@
 // ds_read_b128 per lane at lane_base + compile-time offset (pixel units are 16 bytes, consecutive pixels are
 // consecutive units => conflict-free; for a row's missing left/right neighbours the edge lanes read an all-zero LDS
 // region at the same bank offset instead), so the inner loop is ds_read_b128 + MFMA only.
-// Epilogue: bias, ELU, round to bf16, 8-byte stores that pair up (k halves) into contiguous 512-byte runs.
+// Epilogue: bias, ELU, round to bf16, two 16-byte stores per pixel tile (the MFMA rows are permuted at pack time so a
+// lane holds 16 consecutive couts); the 32 lanes of a k half cover 512 contiguous bytes.
 //
 // Roofline: 2*128*128*9*121 = 35.7 MFLOP per position and convolution on 2.5 PFLOP/s dense bf16 MFMA;
 // per position a workgroup reads 36 KB (+36 KB PROJ) and writes 31 KB of HBM: 8192 positions x 16 convolutions

@@ -57,7 +57,9 @@ int af_tower_stem(af_tower* t, void* stream, const float* planes_dev, void* x_de
  * vin_dev bf16 [batch][4*S*S], pin_dev bf16 [batch][16*S*S]. */
 int af_tower_heads(af_tower* t, void* stream, const void* x_dev, void* vin_dev, void* pin_dev, int32_t batch);
 
-/* A/B knobs (process-global): key 0 = B-fragment ring depth (8, 12, 16), key 1 = persistent workgroups (0 = one per CU). */
+/* A/B knobs (process-global): key 0 = B-fragment ring depth (0 = per-kernel default, 8, 12, 16), key 1 = persistent
+ * workgroups (0 = one per CU), key 2 = profiling ablation bits (results wrong by design: 1 no re-staging, 2 no stores,
+ * 8 no LDS reads). */
 int af_tower_tune(int32_t key, int32_t value);
 
 int64_t af_tower_flops_per_position(const af_tower* t);   /* 2*MAC of the tower, direct convolution */
