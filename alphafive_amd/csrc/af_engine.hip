@@ -35,17 +35,19 @@
 typedef unsigned long long u64;
 
 enum { PH_IDLE = 0, PH_MOVE_START = 1, PH_SEARCH = 2, PH_MOVE_DONE = 3, PH_ERROR = 4 };
-enum { CT_SIMS = 0, CT_SELECTS, CT_EXPANDS, CT_TERMINALS, CT_PLIES, CT_EPISODES, CT_LSUM, CT_LEXP, CT_N };
+enum { CT_SIMS = 0, CT_SELECTS, CT_EXPANDS, CT_TERMINALS, CT_PLIES, CT_EPISODES, CT_LSUM, CT_LEXP,
+       CT_GC, CT_GC_SCANNED, CT_YIELDS, CT_STALLS, CT_N };
+enum { HIST_WORK = 0, HIST_TIME = 64, HIST_MAXTIME = 96, HIST_N = 97 };   // selects per launch | 8-us wave-time bins | max wave time (10 ns units)
 
 struct EngineParams {
-    int G, S, C, goal, sims, upper, training, mode, node_cap, max_ply;
+    int G, S, C, goal, sims, upper, training, mode, node_cap, max_ply, budget;
     uint32_t hash_mask;
     double init_temp, tau_decay, tau_decay_r, alpha, c_puct;
     float c_puct32;
     uint32_t k0, seed_hi, first_game_id;
     u64 colmask[4], boardmask[4];
     // per-game state
-    int32_t *phase, *pending, *sims_left, *ply, *root_last, *nodes, *depth, *leaf_last, *leaf_slot, *status, *random_a;
+    int32_t *phase, *pending, *sims_left, *ply, *root_last, *nodes, *nfree, *depth, *leaf_last, *leaf_slot, *status, *random_a;
     int32_t *action, *has_policy, *visits;
     float* policy;
     u64 *root, *leaf;
@@ -55,7 +57,8 @@ struct EngineParams {
     // transposition store
     uint32_t* hash;
     u64* node_key;
-    int32_t* node_sum;
+    int32_t* node_sum;    // sum_n; -1 = slot is free (dropped by the collector)
+    int32_t* free_idx;    // [G][cap] stack of free slots below the high-water mark `nodes`
     int32_t* edge_n;
     float *edge_w, *edge_p;
     // finished-episode double buffers
@@ -67,6 +70,7 @@ struct EngineParams {
     int32_t *rec_visits, *rec_last, *rec_action;
     u64* counters;
     u64* progress;   // [0] plies committed, [1] episodes finished (all games)
+    u64* hist;       // HIST_N words, all games
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
 
     int phase = rfli(P.phase[g]);
     if (phase == PH_IDLE || phase == PH_MOVE_DONE || phase == PH_ERROR) return;
+    const u64 t_start = wall_clock64();
 
     // ---- load game state (wave-uniform) ----
     u64 root_m[KW], root_t[KW];
@@ -289,20 +294,22 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     int root_last = rfli(P.root_last[g]);
     int sims_left = rfli(P.sims_left[g]);
     int ply = rfli(P.ply[g]);
-    int nodes = rfli(P.nodes[g]);
+    int nodes = rfli(P.nodes[g]);      // high-water mark of the node pool
+    int nfree = rfli(P.nfree[g]);      // free slots below it (left by the collector)
     double tau = P.tau[g];
     uint32_t episode = rfl32(P.episode[g]);
     uint32_t sel = rfl32(P.sel[g]);
     uint32_t plyctr = rfl32(P.plyctr[g]);
     const int random_a = rfli(P.random_a[g]);
     const uint32_t k0 = P.k0, k1 = P.seed_hi + (P.first_game_id + (uint32_t)g);
-    u64 ct[CT_N];
+    uint32_t ct[CT_N];   // this launch's share of the per-game counters
 #pragma unroll
     for (int i = 0; i < CT_N; ++i) ct[i] = 0;
     int err = 0;
 
     u64* const nkeys = P.node_key + (size_t)g * NCAP * (2 * KW);
     int32_t* const nsum = P.node_sum + (size_t)g * NCAP;
+    int32_t* const fre = P.free_idx + (size_t)g * NCAP;
     int32_t* const en = P.edge_n + (size_t)g * NCAP * CP;
     float* const ew = P.edge_w + (size_t)g * NCAP * CP;
     float* const ep = P.edge_p + (size_t)g * NCAP * CP;
@@ -348,10 +355,11 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             for (int l = 0; l < 64; ++l) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk[k]), l));
         }
         if (!((double)s >= 1e-5)) s = (float)1e-5;
-        if (nodes >= NCAP || slot == 0xffffffffu) {
+        if ((nfree == 0 && nodes >= NCAP) || slot == 0xffffffffu) {
             err = AF_ERR_NODE_CAP;
         } else {
-            const int idx = nodes++;
+            int idx;
+            if (nfree > 0) idx = rfli(fre[--nfree]); else idx = nodes++;
             if (lane < 2 * KW) nkeys[(size_t)idx * 2 * KW + lane] = key_word<KW>(lm, lt, lane);
             if (lane == 0) { nsum[idx] = 0; slots[slot] = (uint32_t)idx + 1u; }
 #pragma unroll
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             __syncthreads();
             backup(depth, rflf(value_in[g]), 1);
             ct[CT_EXPANDS]++;
-            ct[CT_LEXP] += (u64)bb_count<KW>(legal);
+            ct[CT_LEXP] += (uint32_t)bb_count<KW>(legal);
         }
         ct[CT_SIMS]++;
         sims_left--;
@@ -372,56 +380,70 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
 
     int status = AF_STATUS_IDLE;
     bool parked = false;
+    int work = 0;   // selects done in this launch
 
     // ---- 2. advance until the game parks ----
     while (!parked && !err) {
+        // A launch lasts as long as its slowest game.  Simulations that end in a terminal position need no
+        // evaluation, so a game whose root has a decided child could run hundreds of them back to back while
+        // every other wave has long parked; after `budget` selects the game yields at the next simulation
+        // boundary instead (its slot of the leaf batch idles for one tick; the order of simulations inside
+        // the game, and so every result, is unchanged).
+        if (work >= P.budget) { status = AF_STATUS_YIELD; parked = true; ct[CT_YIELDS]++; break; }
         if (phase == PH_MOVE_START) {
+            // SELFPLAY back-pressure (the reference's Queue(50), main.py:51,94): an episode may only start
+            // when its record buffer has been popped; until then the game waits here.
+            if (P.mode == AF_MODE_SELFPLAY && ply == 0 && rfl32(P.ep_seq[g]) - rfl32(P.ep_popped[g]) >= 2u) {
+                status = AF_STATUS_YIELD; parked = true; ct[CT_STALLS]++;
+                break;
+            }
             // capacity pressure: drop nodes whose stones are not a superset of the root's (they can
-            // never be reached again: play only adds stones; the reference never revisits them either)
-            if (nodes + P.sims + 2 > NCAP && nodes > 0) {
-                const int rc = bb_count<KW>(root_m) + bb_count<KW>(root_t);
-                int dst = 0;
-                for (int i = 0; i < nodes; ++i) {
-                    u64 nm[KW], nt[KW];
-#pragma unroll
-                    for (int k = 0; k < KW; ++k) { nm[k] = rfl64(nkeys[(size_t)i * 2 * KW + k]); nt[k] = rfl64(nkeys[(size_t)i * 2 * KW + KW + k]); }
-                    const int nc = bb_count<KW>(nm) + bb_count<KW>(nt);
-                    bool keep = true;
-                    // colour of "mine" is fixed by stone-count parity
-#pragma unroll
-                    for (int k = 0; k < KW; ++k) {
-                        const u64 a = ((nc ^ rc) & 1) ? nt[k] : nm[k];
-                        const u64 b = ((nc ^ rc) & 1) ? nm[k] : nt[k];
-                        keep = keep && ((a & root_m[k]) == root_m[k]) && ((b & root_t[k]) == root_t[k]);
-                    }
-                    if (keep) {
-                        if (dst != i) {
-                            if (lane < 2 * KW) nkeys[(size_t)dst * 2 * KW + lane] = key_word<KW>(nm, nt, lane);
-                            if (lane == 0) nsum[dst] = nsum[i];
-#pragma unroll
-                            for (int k = 0; k < KW; ++k) {
-                                const size_t so = (size_t)i * CP + lane + 64 * k, d_ = (size_t)dst * CP + lane + 64 * k;
-                                en[d_] = en[so]; ew[d_] = ew[so]; ep[d_] = ep[so];
-                            }
-                        }
-                        ++dst;
-                    }
-                }
-                nodes = dst;
+            // never be reached again: play only adds stones; the reference never revisits them either).
+            // Wave-parallel mark phase, 64 nodes per step: nothing moves — dropped slots go on the
+            // game's free stack (reused by later expands) and the hash is rebuilt from the survivors.
+            bool collected = false;
+            if (nodes - nfree + P.sims + 2 > NCAP && nodes > 0) {
                 for (uint32_t s_ = lane; s_ <= P.hash_mask; s_ += 64) slots[s_] = 0;
                 __syncthreads();
-                for (int i = lane; i < nodes; i += 64) {
-                    u64 nm[KW], nt[KW];
+                const int rc = bb_count<KW>(root_m) + bb_count<KW>(root_t);
+                int nf = 0;
+                for (int base = 0; base < nodes; base += 64) {
+                    const int i = base + lane;
+                    const bool valid = i < nodes;
+                    bool keep = false;
+                    if (valid && nsum[i] >= 0) {
+                        u64 nm[KW], nt[KW];
 #pragma unroll
-                    for (int k = 0; k < KW; ++k) { nm[k] = nkeys[(size_t)i * 2 * KW + k]; nt[k] = nkeys[(size_t)i * 2 * KW + KW + k]; }
-                    uint32_t h = key_hash<KW>(nm, nt);
-                    for (;;) {
-                        h &= P.hash_mask;
-                        if (atomicCAS(&slots[h], 0u, (uint32_t)i + 1u) == 0u) break;
-                        ++h;
+                        for (int k = 0; k < KW; ++k) { nm[k] = nkeys[(size_t)i * 2 * KW + k]; nt[k] = nkeys[(size_t)i * 2 * KW + KW + k]; }
+                        const int nc = bb_count<KW>(nm) + bb_count<KW>(nt);
+                        keep = true;
+                        // colour of "mine" is fixed by stone-count parity
+#pragma unroll
+                        for (int k = 0; k < KW; ++k) {
+                            const u64 a = ((nc ^ rc) & 1) ? nt[k] : nm[k];
+                            const u64 b = ((nc ^ rc) & 1) ? nm[k] : nt[k];
+                            keep = keep && ((a & root_m[k]) == root_m[k]) && ((b & root_t[k]) == root_t[k]);
+                        }
+                        if (keep) {
+                            uint32_t h = key_hash<KW>(nm, nt);
+                            for (;;) {
+                                h &= P.hash_mask;
+                                if (atomicCAS(&slots[h], 0u, (uint32_t)i + 1u) == 0u) break;
+                                ++h;
+                            }
+                        } else {
+                            nsum[i] = -1;
+                        }
                     }
+                    const u64 dm = __ballot(valid && !keep);
+                    if (valid && !keep) fre[nf + __popcll(dm & ((1ull << lane) - 1ull))] = i;
+                    nf += __popcll(dm);
                 }
+                nfree = nf;
                 __syncthreads();
+                __threadfence();   // the inserts were L2 atomics: drop this CU's cached copies of the table
+                ct[CT_GC]++; ct[CT_GC_SCANNED] += (uint32_t)nodes;
+                collected = true;
             }
             uint32_t slot;
             const int ridx = tree_lookup<KW>(P, g, root_m, root_t, lane, &slot);
@@ -429,6 +451,8 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             if (ridx >= 0) { const int rem = P.upper - rfli(nsum[ridx]); num = rem < num ? rem : num; }
             sims_left = num;
             phase = PH_SEARCH;
+            // the collector is this launch's work: search resumes at the next tick
+            if (collected) { status = AF_STATUS_YIELD; parked = true; ct[CT_YIELDS]++; break; }
         }
 
         if (sims_left <= 0) {
@@ -565,7 +589,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 if (lane == 0) atomicAdd(&P.progress[1], 1ull);
                 for (uint32_t s_ = lane; s_ <= P.hash_mask; s_ += 64) slots[s_] = 0;
                 __syncthreads();
-                nodes = 0;
+                nodes = 0; nfree = 0;
 #pragma unroll
                 for (int k = 0; k < KW; ++k) { root_m[k] = 0; root_t[k] = 0; }
                 root_last = -1;
@@ -692,8 +716,9 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 cell = bb_select<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1));
             }
             cell = rfli(cell);
+            ++work;
             ct[CT_SELECTS]++;
-            ct[CT_LSUM] += (u64)bb_count<KW>(legal);
+            ct[CT_LSUM] += (uint32_t)bb_count<KW>(legal);
             if (lane == 0) { pnode[depth] = idx; pcell[depth] = cell; }
             ++depth;
             // utils.py:275 step
@@ -720,12 +745,19 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         P.sims_left[g] = sims_left;
         P.ply[g] = ply;
         P.nodes[g] = nodes;
+        P.nfree[g] = nfree;
         P.tau[g] = tau;
         P.episode[g] = episode;
         P.sel[g] = sel;
         P.plyctr[g] = plyctr;
         P.status[g] = status;
-        for (int i = 0; i < CT_N; ++i) P.counters[(size_t)g * CT_N + i] += ct[i];
+        for (int i = 0; i < CT_N; ++i) P.counters[(size_t)g * CT_N + i] += (u64)ct[i];
+        // launch-shape evidence: selects per launch and the wave's lifetime (100 MHz constant clock)
+        const u64 dt = wall_clock64() - t_start;
+        atomicAdd(&P.hist[HIST_WORK + (work < 63 ? work : 63)], 1ull);
+        const u64 tb = dt / 800ull;
+        atomicAdd(&P.hist[HIST_TIME + (tb < 31ull ? tb : 31ull)], 1ull);
+        atomicMax(&P.hist[HIST_MAXTIME], dt);
     }
 }
 
@@ -737,7 +769,7 @@ struct af_engine {
     int device;
     int KW;
     std::vector<void*> allocs;
-    std::vector<int32_t> h_i32;
+    std::vector<int32_t> h_i32, h_i32b;
     std::vector<uint32_t> h_seq, h_popped;
     std::vector<u64> h_ct;
 };
@@ -787,6 +819,8 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     P.G = num_games; P.S = S; P.C = C; P.goal = cfg->goal;
     P.sims = cfg->simulation_per_step; P.upper = cfg->upper_simulation_per_step;
     P.training = training ? 1 : 0; P.mode = mode; P.max_ply = C;
+    P.budget = AF_DEFAULT_TICK_BUDGET;
+    if (const char* b = getenv("AF_TICK_BUDGET")) { const int v = atoi(b); if (v > 0) P.budget = v; }
     if (node_cap <= 0) node_cap = mode == AF_MODE_SELFPLAY ? 4 * P.sims + 64 : 32768;
     if (node_cap < P.sims + 8) node_cap = P.sims + 8;
     P.node_cap = node_cap;
@@ -803,13 +837,13 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     const size_t G = num_games;
     int rc = AF_OK;
 #define A(p, n) if (rc == AF_OK) rc = dalloc(e, &P.p, (n))
-    A(phase, G); A(pending, G); A(sims_left, G); A(ply, G); A(root_last, G); A(nodes, G); A(depth, G);
+    A(phase, G); A(pending, G); A(sims_left, G); A(ply, G); A(root_last, G); A(nodes, G); A(nfree, G); A(depth, G);
     A(leaf_last, G); A(leaf_slot, G); A(status, G); A(random_a, G); A(action, G); A(has_policy, G);
     A(visits, G * CP); A(policy, G * CP); A(root, G * 2 * KW); A(leaf, G * 2 * KW); A(tau, G);
     A(episode, G); A(sel, G); A(plyctr, G); A(path_node, G * CP); A(path_cell, G * CP);
-    A(hash, G * hcap); A(node_key, G * node_cap * 2 * KW); A(node_sum, G * node_cap);
+    A(hash, G * hcap); A(node_key, G * node_cap * 2 * KW); A(node_sum, G * node_cap); A(free_idx, G * node_cap);
     A(edge_n, G * node_cap * CP); A(edge_w, G * node_cap * CP); A(edge_p, G * node_cap * CP);
-    A(ep_seq, G); A(ep_popped, G); A(counters, G * CT_N); A(progress, 2);
+    A(ep_seq, G); A(ep_popped, G); A(counters, G * CT_N); A(progress, 2); A(hist, HIST_N);
     if (mode == AF_MODE_SELFPLAY) {
         const size_t R = G * 2 * P.max_ply;
         A(ep_len, G * 2); A(ep_final, G * 2); A(rec_key, R * 2 * KW); A(rec_policy, R * C); A(rec_visits, R * C);
@@ -823,7 +857,7 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     HIP_OK(hipMemcpy(P.phase, ph.data(), G * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(P.root_last, rl.data(), G * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(P.tau, tau.data(), G * 8, hipMemcpyHostToDevice));
-    e->h_i32.resize(G); e->h_seq.resize(G); e->h_popped.assign(G, 0); e->h_ct.resize(G * CT_N);
+    e->h_i32.resize(G); e->h_i32b.resize(G); e->h_seq.resize(G); e->h_popped.assign(G, 0); e->h_ct.resize(G * CT_N);
     *out = e;
     return AF_OK;
 }
@@ -875,6 +909,7 @@ int af_engine_set_root(af_engine* e, int32_t game, const uint64_t* key, int32_t 
         HIP_OK(hipMemset(P.hash + (size_t)game * hcap, 0, hcap * 4));
         int32_t zero = 0;
         HIP_OK(hipMemcpy(P.nodes + game, &zero, 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(P.nfree + game, &zero, 4, hipMemcpyHostToDevice));
         double tau = P.init_temp;
         HIP_OK(hipMemcpy(P.tau + game, &tau, 8, hipMemcpyHostToDevice));
         uint32_t ep;
@@ -955,12 +990,30 @@ int af_engine_counters(af_engine* e, void* stream, uint64_t* out) {
     const int G = e->P.G;
     HIP_OK(hipMemcpyAsync(e->h_ct.data(), e->P.counters, (size_t)G * CT_N * 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(e->h_i32.data(), e->P.nodes, (size_t)G * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(e->h_i32b.data(), e->P.nfree, (size_t)G * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    for (int i = 0; i <= CT_N; ++i) out[i] = 0;
+    for (int i = 0; i < AF_NUM_COUNTERS; ++i) out[i] = 0;
+    // out[0..7] as ABI v1, out[8] = live nodes, out[9..12] = collector runs, slots scanned, yields, stalls
     for (int g = 0; g < G; ++g) {
-        for (int i = 0; i < CT_N; ++i) out[i] += e->h_ct[(size_t)g * CT_N + i];
-        out[CT_N] += (uint64_t)e->h_i32[g];
+        for (int i = 0; i < 8; ++i) out[i] += e->h_ct[(size_t)g * CT_N + i];
+        for (int i = 8; i < CT_N; ++i) out[i + 1] += e->h_ct[(size_t)g * CT_N + i];
+        out[8] += (uint64_t)(e->h_i32[g] - e->h_i32b[g]);
     }
+    return AF_OK;
+}
+
+int af_engine_tick_histogram(af_engine* e, void* stream, uint64_t* out, int32_t reset) {
+    if (!e || !out) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemcpyAsync(out, e->P.hist, (size_t)HIST_N * 8, hipMemcpyDeviceToHost, st));
+    if (reset) HIP_OK(hipMemsetAsync(e->P.hist, 0, (size_t)HIST_N * 8, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return AF_OK;
+}
+
+int af_engine_set_tick_budget(af_engine* e, int32_t selects_per_launch) {
+    if (!e || selects_per_launch < 1) return AF_ERR_ARG;
+    e->P.budget = selects_per_launch;
     return AF_OK;
 }
 
@@ -978,27 +1031,36 @@ int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys,
     EngineParams& P = e->P;
     const int KW2 = 2 * e->KW, CP = 64 * e->KW, C = P.C;
     HIP_OK(hipDeviceSynchronize());
-    int32_t cnt;
-    HIP_OK(hipMemcpy(&cnt, P.nodes + game, 4, hipMemcpyDeviceToHost));
-    const int m = cnt < cap ? cnt : cap;
-    if (m <= 0) return cnt;
-    std::vector<int32_t> bn((size_t)m * CP);
-    std::vector<float> bw((size_t)m * CP), bp((size_t)m * CP);
+    int32_t hw;
+    HIP_OK(hipMemcpy(&hw, P.nodes + game, 4, hipMemcpyDeviceToHost));
     const size_t nb = (size_t)game * P.node_cap;
-    HIP_OK(hipMemcpy(keys, P.node_key + nb * KW2, (size_t)m * KW2 * 8, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(sum_n, P.node_sum + nb, (size_t)m * 4, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(bn.data(), P.edge_n + nb * CP, (size_t)m * CP * 4, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(bw.data(), P.edge_w + nb * CP, (size_t)m * CP * 4, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(bp.data(), P.edge_p + nb * CP, (size_t)m * CP * 4, hipMemcpyDeviceToHost));
-    for (int i = 0; i < m; ++i)
+    std::vector<int32_t> bs((size_t)(hw > 0 ? hw : 1));
+    if (hw > 0) HIP_OK(hipMemcpy(bs.data(), P.node_sum + nb, (size_t)hw * 4, hipMemcpyDeviceToHost));
+    int live = 0;
+    for (int i = 0; i < hw; ++i) live += bs[i] >= 0;
+    if (cap < live || live == 0) return live;        // size query (or nothing to copy)
+    std::vector<int32_t> bn((size_t)hw * CP);
+    std::vector<float> bw((size_t)hw * CP), bp((size_t)hw * CP);
+    std::vector<uint64_t> bk((size_t)hw * KW2);
+    HIP_OK(hipMemcpy(bk.data(), P.node_key + nb * KW2, (size_t)hw * KW2 * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(bn.data(), P.edge_n + nb * CP, (size_t)hw * CP * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(bw.data(), P.edge_w + nb * CP, (size_t)hw * CP * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(bp.data(), P.edge_p + nb * CP, (size_t)hw * CP * 4, hipMemcpyDeviceToHost));
+    int o = 0;
+    for (int i = 0; i < hw; ++i) {
+        if (bs[i] < 0) continue;                     // slot freed by the collector
+        for (int k = 0; k < KW2; ++k) keys[(size_t)o * KW2 + k] = bk[(size_t)i * KW2 + k];
+        sum_n[o] = bs[i];
         for (int c = 0; c < C; ++c) {
             const int32_t raw = bn[(size_t)i * CP + c];
-            n[(size_t)i * C + c] = raw & 0x7fffffff;
-            f32[(size_t)i * C + c] = raw < 0 ? 1 : 0;
-            w[(size_t)i * C + c] = bw[(size_t)i * CP + c];
-            p[(size_t)i * C + c] = bp[(size_t)i * CP + c];
+            n[(size_t)o * C + c] = raw & 0x7fffffff;
+            f32[(size_t)o * C + c] = raw < 0 ? 1 : 0;
+            w[(size_t)o * C + c] = bw[(size_t)i * CP + c];
+            p[(size_t)o * C + c] = bp[(size_t)i * CP + c];
         }
-    return cnt;
+        ++o;
+    }
+    return live;
 }
 
 // utils.py:178-196 state_to_board, straight into a key

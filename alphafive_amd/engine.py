@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.environ.get("AF_HIP_LIB") or os.path.join(_PKG, "_lib", "libaf_hip.so")
 
 MODE_SELFPLAY, MODE_EXTERNAL = 0, 1
-STATUS_IDLE, STATUS_NEED_EVAL, STATUS_MOVE_DONE = 0, 1, 2
+STATUS_IDLE, STATUS_NEED_EVAL, STATUS_MOVE_DONE, STATUS_YIELD = 0, 1, 2, 3
 BLACK_WIN, WHITE_WIN, DRAW = 1, -1, 0          # utils.py:9-11
 
 CFG_ATTRS = ("board_size", "goal", "simulation_per_step", "upper_simulation_per_step", "init_temp", "gamma",
@@ -69,6 +69,8 @@ def lib():
         L.af_engine_pop_episodes.argtypes = [vp, vp, C.c_int32, i32p, f32p, u64p, f32p, i32p, i32p, i32p]
         L.af_engine_counters.argtypes = [vp, vp, u64p]
         L.af_engine_progress.argtypes = [vp, vp, u64p]
+        L.af_engine_tick_histogram.argtypes = [vp, vp, u64p, C.c_int32]
+        L.af_engine_set_tick_budget.argtypes = [vp, C.c_int32]
         L.af_engine_tree_dump.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
         L.af_state_to_key.argtypes = [C.c_char_p, C.c_int32, u64p]
         L.af_key_to_state.argtypes = [u64p, C.c_int32, C.c_char_p, C.c_int32]
@@ -104,7 +106,7 @@ def key_to_state(key, S):
 
 
 COUNTER_NAMES = ("sims", "selects", "expands", "terminals", "plies", "episodes", "legal_sum", "legal_sum_expand",
-                 "nodes")
+                 "nodes", "collector_runs", "collector_scanned", "yields", "stalls")
 
 
 class Engine:
@@ -159,9 +161,20 @@ class Engine:
         return a.value, (pol if hp.value else None), vis, tau.value
 
     def counters(self, stream=None):
-        out = np.zeros(9, np.uint64)
+        out = np.zeros(len(COUNTER_NAMES), np.uint64)
         _check(lib().af_engine_counters(self._h, stream, _p(out, C.c_uint64)), "af_engine_counters")
         return {k: int(v) for k, v in zip(COUNTER_NAMES, out)}
+
+    def tick_histogram(self, stream=None, reset=False):
+        """-> dict(selects=int64[64] games per selects-in-one-launch, wave_us=int64[32] games per 8-us bin of
+        wave lifetime, max_wave_us=float): the launch-shape evidence of include/af_engine.h."""
+        out = np.zeros(97, np.uint64)
+        _check(lib().af_engine_tick_histogram(self._h, stream, _p(out, C.c_uint64), int(reset)), "tick_histogram")
+        return dict(selects=out[:64].astype(np.int64), wave_us=out[64:96].astype(np.int64),
+                    max_wave_us=float(out[96]) * 0.01)
+
+    def set_tick_budget(self, selects_per_launch):
+        _check(lib().af_engine_set_tick_budget(self._h, int(selects_per_launch)), "af_engine_set_tick_budget")
 
     def progress(self, stream=None):
         out = np.zeros(2, np.uint64)

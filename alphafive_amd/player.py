@@ -156,6 +156,8 @@ class Player(object):
                 self._evaluate_leaf()
             elif st == _eng.STATUS_MOVE_DONE:
                 break
+            elif st == _eng.STATUS_YIELD:          # per-launch work budget used up: nothing to evaluate
+                continue
             else:
                 raise _eng.EngineError(f"unexpected engine status {st}")
         action, policy, visits, tau = self._engine.move_result(0)

@@ -260,6 +260,7 @@ def main():
     barrier()
     ct0 = sp.counters()
     p0 = sp.progress()[0]
+    sp.engine.tick_histogram(stream, reset=True)
     timing["on"] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -269,6 +270,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timing["on"] = False
     ct1 = sp.counters()
+    hist = sp.engine.tick_histogram(stream)
     plies = sp.progress()[0] - p0
 
     tot = torch.tensor([float(plies)], device=comm_dev, dtype=torch.float64)
@@ -332,7 +334,13 @@ def main():
                               "ms_per_launch": tick_ms, "bytes_per_launch": tree_bytes(d, C) / n_ticks,
                               "peak_measured_copy": copy_gbs, "frac_of_measured_copy": tree_gbs / copy_gbs,
                               "note": "SURVEY 8d bound (HBM); PMC (profiles/r1_16) shows the kernel limited by per-game serial latency and fp64 VALU work of the noise generator"},
-            "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms},
+            "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms,
+                           "tree_ms_max": float(np.max([a.elapsed_time(b) for a, b in ev_tick])),
+                           "tree_ms_p50": float(np.median([a.elapsed_time(b) for a, b in ev_tick]))},
+            "tick_shape": {"selects_per_game_and_launch_hist": hist["selects"].tolist(),
+                           "wave_lifetime_8us_bins": hist["wave_us"].tolist(), "max_wave_us": hist["max_wave_us"],
+                           "collector_runs": d["collector_runs"], "collector_slots_scanned": d["collector_scanned"],
+                           "yields": d["yields"], "stalls": d["stalls"]},
         }
         if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, weights if cfg.board_size == 11 else None)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 1
+#define AF_ABI_VERSION 2
 
 /* engine modes */
 #define AF_MODE_SELFPLAY 0   /* Player.run loop on device: games restart forever (main.py:82 gen_data) */
@@ -39,6 +39,12 @@ extern "C" {
 #define AF_STATUS_IDLE      0
 #define AF_STATUS_NEED_EVAL 1   /* a leaf's input planes were written; feed policy/value to the next tick */
 #define AF_STATUS_MOVE_DONE 2   /* EXTERNAL mode: read af_engine_move_result, then set the next root */
+#define AF_STATUS_YIELD     3   /* the game used up its per-launch work budget (or ran its store collector, or waits
+                                 * for its finished episodes to be popped): nothing to evaluate, tick again */
+
+/* selects a game may do in one launch before it yields at the next simulation boundary (a launch lasts as long
+ * as its slowest game; simulations that end in terminal positions never park).  Results do not depend on it. */
+#define AF_DEFAULT_TICK_BUDGET 8
 
 /* error codes */
 #define AF_OK 0
@@ -112,8 +118,19 @@ int af_engine_pop_episodes(af_engine* e, void* stream, int32_t cap, int32_t* met
                            uint64_t* keys, float* policies, int32_t* visits, int32_t* lasts, int32_t* actions);
 
 /* counters summed over games: out[0..8] = sims, selects, expands, terminal hits, plies,
- * episodes, sum of L over selects, sum of L over expands, nodes currently stored */
+ * episodes, sum of L over selects, sum of L over expands, nodes currently stored;
+ * out[9..12] = store-collector runs, node slots it scanned, yields, episode-buffer stalls */
+#define AF_NUM_COUNTERS 13
 int af_engine_counters(af_engine* e, void* stream, uint64_t* out);
+
+/* launch-shape evidence, accumulated over all games and launches since the last reset:
+ * out[0..63] = histogram of selects per game and launch (63 = 63 or more), out[64..95] = histogram of
+ * a game's wave lifetime in 8-us bins (31 = 248 us or more), out[96] = longest wave lifetime in 10-ns units */
+#define AF_HIST_WORDS 97
+int af_engine_tick_histogram(af_engine* e, void* stream, uint64_t* out, int32_t reset);
+
+/* override AF_DEFAULT_TICK_BUDGET (also settable through the environment: AF_TICK_BUDGET) */
+int af_engine_set_tick_budget(af_engine* e, int32_t selects_per_launch);
 
 /* cheap progress poll (16-byte copy): out[0] = plies committed, out[1] = episodes finished */
 int af_engine_progress(af_engine* e, void* stream, uint64_t* out);
