@@ -11,13 +11,14 @@ REPO = os.path.dirname(PKG)
 LIBDIR = os.path.join(PKG, "_lib")
 ARCH = "gfx950"
 
-HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(REPO, "include")]
+HIPCC_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(REPO, "include"),
+               "-I", os.path.join(PKG, "csrc")]
 
 # name -> (sources, extra flags).  -ffp-contract=off: the tree engine's arithmetic must be
 # exactly as written; the net kernels are free to contract (fp32 MFMA is an fma chain).
 TARGETS = {
     "libaf_hip.so": (["csrc/af_engine.hip"], ["-ffp-contract=off"]),
-    "libaf_net.so": (["csrc/af_net.hip"], []),
+    "libaf_net.so": (["csrc/af_net.hip", "csrc/af_conv_f16s.hip"], []),
     "libaf_tower.so": (["csrc/af_tower_bf16.hip"], []),
     "libaf_replay.so": (["csrc/af_replay.hip"], []),
 }
@@ -27,6 +28,7 @@ def _stale(out, srcs):
     if not os.path.exists(out):
         return True
     deps = list(srcs) + [os.path.join(REPO, "include", f) for f in os.listdir(os.path.join(REPO, "include"))]
+    deps += [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc")) if f.endswith(".h")]
     return any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 

@@ -1,0 +1,25 @@
+// af_conv_f16s.h — internal interface (inside libaf_net.so) between af_net.hip and af_conv_f16s.hip: the fp16
+// split-operand convolution path of the 11x11 network.  Not part of the C ABI (include/af_net.h is).
+#ifndef AF_CONV_F16S_H
+#define AF_CONV_F16S_H
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+struct f16s_net;
+
+// variables under their checkpoint names in TF layout (as af_net_set_variable received them); 11x11 boards only
+int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::string, std::vector<float>>& vars);
+void f16s_destroy(f16s_net* n);
+// stem + bone/block1 + bone/block2 on stream st
+int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes_dev, int batch);
+// value/block3 -> o3, policy/block4+5 -> o5: fp32 planes [batch][32][PP], pixel (y,x) at (y+1)*WP + x+1 (the head kernels' input)
+int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3_dev, int WP, int PP);
+int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5_dev, int WP, int PP);
+void f16s_set_ablation(f16s_net* n, int bits);
+int f16s_read_activation(f16s_net* n, int which, int batch, float* host);
+
+#endif

@@ -1,0 +1,542 @@
+// af_conv_f16s.hip — the 3x3 convolutions of the reference network (genData/network.py:52-56: residual(f,u) =
+// ELU(conv1x1(f) + conv3x3(ELU(conv3x3(f))))) as implicit GEMMs on the fp16 matrix cores with fp32-class accuracy.
+//
+// Arithmetic ("fp16 split operands"): every fp32 operand x is carried as two halves, x = hi + lo with
+// hi = fp16(x), lo = fp16(x - hi) (22 mantissa bits; the MFMA keeps fp16 denormals, probed on gfx950), and a
+// product is three v_mfma_f32_32x32x16_f16 with fp32 accumulation:  W_hi*X_hi + W_hi*X_lo + W_lo*X_hi  (the dropped
+// W_lo*X_lo term is 2^-22 relative).  That is 16/3 of the fp32 MFMA rate.  Weights are scaled by a power of two per
+// layer so that their halves sit in the fp16 normal range; the epilogue multiplies back (exact).  Measured against
+// the fp64 restatement of the network: |dv| 1.1e-6, |dp| 1.0e-6 (fp32 arithmetic: 4e-7), bar 1e-5.
+//
+// Activations live in HBM already split, in "S32" layout: [position][C/32 slabs][hi|lo][4 unit rows][144 units][8 ch]
+// fp16 — a unit is 8 channels of one pixel (16 bytes = one lane's MFMA B operand), pixel n = 11y + x sits at unit n + 11
+// (rows back to back, 11 zero units above, 12 below; the zeros are never written).  A 32-channel slab is 18,432
+// contiguous bytes.
+//
+// Kernel af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32>: NSM 32-channel slabs of the 3x3 input, NSP slabs of the block input
+// whose 1x1 projection is folded in as extra k-steps.  Weight-stationary and persistent: a workgroup = 4 waves (one per
+// SIMD, 512 registers) = CT cout tiles of 32 x KS halves of every 32-channel slab (k-split: wave ks takes channels
+// 16ks..16ks+15) x PS pixel groups (4/PS tiles of 32 pixels); each wave keeps ALL its weight fragments (hi and lo) in
+// registers for the whole launch and the workgroup walks over positions.  Input slabs stream through a two-slot LDS
+// ring by LDS-DMA (global_load_lds_dwordx4), slab t+1 landing while slab t multiplies; a B fragment is one
+// ds_read_b128 at lane base + immediate (conflict-free: consecutive lanes, consecutive units), the left / right
+// neighbours that fall off a board row are read from an all-zero LDS region through a second base register.
+// k-split partial sums meet through LDS once per position; epilogue: scale, bias, ELU, split, 16-byte stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "af_conv_f16s.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FS_HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[af_conv_f16s] %s failed: %s\n", #x, hipGetErrorString(e_)); return -2; } } while (0)
+
+namespace {
+
+constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;
+constexpr uint32_t kRowB = kPIX * 16u;          // one unit row: 8 channels x 144 units
+constexpr uint32_t kHalfB = 4u * kRowB;         // the hi (or lo) halves of a 32-channel slab
+constexpr uint32_t kSlabB = 2u * kHalfB;        // 18,432 bytes
+constexpr int kPieces = kSlabB / 1024;          // 18 LDS-DMA wave-instructions per slab
+constexpr uint32_t kLds0 = 256u;                // slack so that unit -1 of a slot stays inside LDS
+constexpr uint32_t kZoff = kLds0 + 2u * kSlabB; // all-zero region (edge lanes)
+constexpr uint32_t kBiasOff = kZoff + kSlabB;   // 128 floats
+constexpr uint32_t kScrOff = kBiasOff + 512u;   // k-split exchange
+
+// LDS-DMA: 16 bytes per lane from global memory into LDS at (wave-uniform lds_dst) + lane*16; counted on vmcnt.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+
+struct F16sArgs {
+    const char* in;       // S32, NSM slabs per position
+    const char* in2;      // S32, NSP slabs per position (block input for the folded 1x1 projection)
+    const uint4* w;       // [cout tile][ks][2 * items][64 lanes] A fragments (8 fp16), hi then lo per item
+    const float* bias;    // [COUT] (conv2: conv2 bias + projection bias)
+    char* out;            // S32, COUT/32 slabs per position
+    float* out32;         // OUT32: fp32 [position][COUT][PP] padded planes (the head kernels' input)
+    float inv_scale;      // 1 / weight scale
+    int batch, WP, PP;
+    int abl;              // profiling: bit 0 no LDS-DMA after the first slab, bit 1 no stores
+};
+
+template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32>
+__global__ __launch_bounds__(256, 1) void af_conv_f16s(F16sArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 4 / PS;                    // pixel tiles per wave
+    constexpr int C16 = 2 / KS;                   // 16-channel k-steps per slab and wave
+    constexpr int ITP = C16, ITM = 9 * C16;       // items (k-step x tap) per projection / main slab
+    constexpr int NIT = NSP * ITP + NSM * ITM;    // items per position and wave
+    constexpr int SPP = NSP + NSM;                // slabs per position
+    constexpr int NFIN = NT / KS;                 // tiles a wave finishes (epilogue) after the k-split exchange
+    static_assert(CT * KS * PS == 4 && NT >= KS, "4 waves");
+    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ct = wv % CT, ks = (wv / CT) % KS, ps = wv / (CT * KS);
+    const int ctg = (int)blockIdx.y * CT + ct, nso = (int)gridDim.y * CT;
+    const uint32_t lds = (uint32_t)(uintptr_t)smem;
+
+    int pos = blockIdx.x;
+    if (pos >= A.batch) return;
+
+    auto slab_src = [&](int p, int j) -> const char* {
+        return j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabB : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabB;
+    };
+    auto dma_piece = [&](const char* src, uint32_t slot_off, int q) {       // piece wv + 4q of a slab
+        const int piece = wv + 4 * q;
+        if (piece < kPieces)
+            glds16(src + piece * 1024 + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + piece * 1024u)));
+    };
+
+    for (uint32_t u = threadIdx.x; u < kSlabB / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
+    if (threadIdx.x < kLds0 / 16) *reinterpret_cast<uint4*>(smem + threadIdx.x * 16) = uint4{0, 0, 0, 0};   // the slack below slot 0
+    if (threadIdx.x < CT * 32) reinterpret_cast<float*>(smem + kBiasOff)[threadIdx.x] = A.bias[(int)blockIdx.y * CT * 32 + threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) dma_piece(slab_src(pos, 0), 0u, q);
+
+    // resident weights: 2 * NIT fragments
+    h8 W[2 * NIT];
+    {
+        const uint4* wp = A.w + ((size_t)(ctg * KS + ks) * (2 * NIT)) * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < 2 * NIT; ++f) {
+            const uint4 v = wp[f * 64];
+            __builtin_memcpy(&W[f], &v, 16);
+        }
+    }
+    // lane geometry per pixel tile: LDS byte base of tap (0,0) in slot 0, zero-region twin, output unit
+    uint32_t lb[NT], zb[NT];
+    int pix[NT];
+    bool ok[NT], edgeL[NT], edgeR[NT];
+#pragma unroll
+    for (int jj = 0; jj < NT; ++jj) {
+        const int n = 32 * (ps * NT + jj) + nn;
+        ok[jj] = n < kNPIX;
+        const int nc = ok[jj] ? n : 0;
+        pix[jj] = nc;
+        const int x = nc % kS;
+        edgeL[jj] = x == 0; edgeR[jj] = x == kS - 1;
+        // pixel nc sits at unit nc + 11; tap (ky,kx) reads unit nc + 11 + (ky-1)*11 + (kx-1) = (nc - 1) + ky*11 + kx
+        lb[jj] = kLds0 + (uint32_t)((KS == 2 ? 2 * ks : 0) + kg) * kRowB + (uint32_t)(nc * 16) - 16u;
+        zb[jj] = kZoff + (lb[jj] & 255u);
+    }
+#pragma unroll
+    for (int f = 0; f < 2 * NIT; ++f) asm volatile("" : "+v"(W[f]));      // pin the weight loads before the loop (see af_tower_bf16.hip)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    uint32_t t = 0;
+    for (; pos < A.batch; pos += gridDim.x) {
+        const int nxt = pos + (int)gridDim.x;
+        const bool more_pos = nxt < A.batch;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[jj][r] = 0.0f;
+
+#pragma clang loop unroll(full)
+        for (int j = 0; j < SPP; ++j) {
+            const bool proj = j < NSP;
+            const int NI = proj ? ITP : ITM;
+            const int ibase = proj ? j * ITP : NSP * ITP + (j - NSP) * ITM;
+            const uint32_t cur = (t & 1u) ? kSlabB : 0u, nx = kSlabB - cur;
+            const bool more = ((j + 1 < SPP) || more_pos) && !(A.abl & 1);
+            const char* nsrc = (j + 1 < SPP) ? slab_src(pos, j + 1) : slab_src(nxt, 0);
+            uint32_t bC[NT], bL[NT], bR[NT];
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) {
+                bC[jj] = lb[jj] + cur;
+                bL[jj] = edgeL[jj] ? zb[jj] : bC[jj];
+                bR[jj] = edgeR[jj] ? zb[jj] : bC[jj];
+            }
+            auto rd = [&](int it, int jj, int p) -> h8 {
+                const int c = proj ? it : it / 9, tap = proj ? 4 : it % 9, ky = tap / 3, kx = tap % 3;
+                const uint32_t base = kx == 0 ? bL[jj] : (kx == 2 ? bR[jj] : bC[jj]);
+                const uint32_t imm = (uint32_t)p * kHalfB + (KS == 1 ? 2u * c * kRowB : 0u) + (uint32_t)(ky * kS + kx) * 16u;
+                return *reinterpret_cast<const h8*>(smem + base + imm);
+            };
+            h8 fr[2][NT][2];
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) { fr[0][jj][0] = rd(0, jj, 0); fr[0][jj][1] = rd(0, jj, 1); }
+#pragma clang loop unroll(full)
+            for (int it = 0; it < NI; ++it) {
+                const int b = it & 1;
+                if (it + 1 < NI) {
+#pragma unroll
+                    for (int jj = 0; jj < NT; ++jj) { fr[b ^ 1][jj][0] = rd(it + 1, jj, 0); fr[b ^ 1][jj][1] = rd(it + 1, jj, 1); }
+                }
+                const h8 wh = W[2 * (ibase + it)], wl = W[2 * (ibase + it) + 1];
+#pragma unroll
+                for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fr[b][jj][0], acc[jj], 0, 0, 0);
+#pragma unroll
+                for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fr[b][jj][1], acc[jj], 0, 0, 0);
+#pragma unroll
+                for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fr[b][jj][0], acc[jj], 0, 0, 0);
+                if (it + 1 < NI) {
+#pragma unroll
+                    for (int q = 0; q < 2 * NT; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
+                }
+                if (it < 5 && more) dma_piece(nsrc, nx, it);               // the next slab: one 1 KB piece per item
+            }
+            if (more) {
+#pragma unroll
+                for (int q = NI; q < 5; ++q) dma_piece(nsrc, nx, q);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next slab has landed ...
+            __builtin_amdgcn_s_barrier();                                    // ... for every wave, and all are done with this one
+            ++t;
+        }
+
+        // k-split: the two waves of a pair exchange the halves they do not finish
+        if (KS == 2) {
+            char* scr = smem + kScrOff + (uint32_t)(ct + CT * ps) * (NT * 4096u);
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) {
+                const bool mine = (jj / NFIN) == ks;
+                if (!mine) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {acc[jj][4 * q], acc[jj][4 * q + 1], acc[jj][4 * q + 2], acc[jj][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(scr + (uint32_t)(jj * 4 + q) * 1024u + lane * 16u) = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) {
+                const bool mine = (jj / NFIN) == ks;
+                if (mine) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(scr + (uint32_t)(jj * 4 + q) * 1024u + lane * 16u);
+                        acc[jj][4 * q] += v[0]; acc[jj][4 * q + 1] += v[1]; acc[jj][4 * q + 2] += v[2]; acc[jj][4 * q + 3] += v[3];
+                    }
+                }
+            }
+        }
+
+        // epilogue: scale back, bias, ELU; split into halves and store (or fp32 planes for the heads).  The weight
+        // rows are packed so that a lane's 16 accumulator rows are the couts 32*ctg + 16*kg + r.
+        float bs[16];
+        {
+            const f32x4* bp = reinterpret_cast<const f32x4*>(smem + kBiasOff + (uint32_t)(32 * ct + 16 * kg) * 4u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const f32x4 v = bp[q]; bs[4 * q] = v[0]; bs[4 * q + 1] = v[1]; bs[4 * q + 2] = v[2]; bs[4 * q + 3] = v[3]; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj) {
+            const bool mine = KS == 1 || (jj / NFIN) == ks;
+            if (!mine) continue;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = elu1(acc[jj][r] * A.inv_scale + bs[r]);
+            if (OUT32) {
+                const int y = pix[jj] / kS, x = pix[jj] - y * kS;
+                float* o = A.out32 + ((size_t)pos * (nso * 32) + 32 * ctg + 16 * kg) * A.PP + (y + 1) * A.WP + x + 1;
+                if (ok[jj] && !(A.abl & 2)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(size_t)r * A.PP] = v[r];
+                }
+            } else {
+                char* o = A.out + ((size_t)pos * nso + ctg) * kSlabB + (uint32_t)(2 * kg) * kRowB + (uint32_t)(pix[jj] + kS) * 16u;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    h8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = v[8 * hf + e];
+                        const _Float16 h = (_Float16)f;
+                        hi[e] = h;
+                        lo[e] = (_Float16)(f - (float)h);
+                    }
+                    if (ok[jj] && !(A.abl & 2)) {
+                        *reinterpret_cast<h8*>(o + hf * kRowB) = hi;
+                        *reinterpret_cast<h8*>(o + hf * kRowB + kHalfB) = lo;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// 5x5 stem (3 -> 32, SAME) + bias + ELU (network.py:63) on the VALU (2,400 MAC per pixel), output split into S32.
+// planes fp32 [B][3][11][11] (utils.py:256 board_to_inputs); w [75][32] HWIO.
+__global__ __launch_bounds__(256) void af_stem_f16s(const float* __restrict__ planes, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, char* __restrict__ out, int batch) {
+    __shared__ float sx[3 * 15 * 15];
+    __shared__ float sw[75 * 32];
+    __shared__ float sb[32];
+    const int t = threadIdx.x;
+    for (int i = t; i < 75 * 32; i += 256) sw[i] = w[i];
+    if (t < 32) sb[t] = bias[t];
+    for (int i = t; i < 3 * 225; i += 256) sx[i] = 0.0f;
+    for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+        __syncthreads();
+        for (int i = t; i < 3 * kNPIX; i += 256) {
+            const int c = i / kNPIX, p = i - c * kNPIX, y = p / kS, x = p - y * kS;
+            sx[c * 225 + (y + 2) * 15 + x + 2] = planes[(size_t)b * 3 * kNPIX + i];
+        }
+        __syncthreads();
+        if (t < kNPIX) {
+            const int y = t / kS, x = t - y * kS;
+            float acc[32];
+#pragma unroll
+            for (int co = 0; co < 32; ++co) acc[co] = sb[co];
+            for (int ky = 0; ky < 5; ++ky)
+                for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float xv = sx[c * 225 + (y + ky) * 15 + x + kx];
+                        const float* wr = sw + ((ky * 5 + kx) * 3 + c) * 32;
+#pragma unroll
+                        for (int co = 0; co < 32; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                    }
+            char* o = out + (size_t)b * kSlabB + (uint32_t)(t + kS) * 16u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                h8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = elu1(acc[8 * u + e]);
+                    const _Float16 h = (_Float16)f;
+                    hi[e] = h;
+                    lo[e] = (_Float16)(f - (float)h);
+                }
+                *reinterpret_cast<h8*>(o + u * kRowB) = hi;
+                *reinterpret_cast<h8*>(o + u * kRowB + kHalfB) = lo;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host ------------------------------------------------------------------
+struct LayerCfg { int cin, cout, pcin, CT, KS, PS, gy; };
+// block b: conv1 = layer 2b, conv2 (+ projection) = layer 2b+1
+const LayerCfg kLayers[10] = {
+    {32, 64, 0, 2, 1, 2, 1},   {64, 64, 32, 2, 1, 2, 1},      // bone/block1
+    {64, 128, 0, 4, 1, 1, 1},  {128, 128, 64, 2, 2, 1, 2},    // bone/block2
+    {128, 32, 0, 1, 2, 2, 1},  {32, 32, 128, 1, 2, 2, 1},     // value/block3
+    {128, 64, 0, 2, 2, 1, 1},  {64, 64, 128, 2, 2, 1, 1},     // policy/block4
+    {64, 32, 0, 1, 2, 2, 1},   {32, 32, 64, 1, 2, 2, 1},      // policy/block5
+};
+const char* const kBlockNames[5] = {"bone/block1", "bone/block2", "value/block3", "policy/block4", "policy/block5"};
+
+template <class T>
+int dev_upload(std::vector<void*>& allocs, T** dst, const void* src, size_t bytes) {
+    void* q = nullptr;
+    FS_HIP_OK(hipMalloc(&q, bytes));
+    FS_HIP_OK(hipMemcpy(q, src, bytes, hipMemcpyHostToDevice));
+    allocs.push_back(q);
+    *dst = (T*)q;
+    return 0;
+}
+
+// A fragments of one layer: [cout tile][ks][item][hi|lo][lane][8]; item order = the kernel's consumption order
+// (projection slabs first; per slab: 16-channel k-step c, then the 9 taps); MFMA row m of a tile holds cout
+// 32*tile + 16*((m>>2)&1) + 8*(m>>4) + 4*((m>>3)&1) + (m&3) so that a lane's 16 accumulator rows are consecutive couts.
+// w3: HWIO [9][cin][cout]; w1: [pcin][cout] or null.
+std::vector<_Float16> pack_layer(const LayerCfg& L, const float* w3, const float* w1, float scale) {
+    const int NSM = L.cin / 32, NSP = L.pcin / 32, C16 = 2 / L.KS;
+    const int NIT = NSP * C16 + NSM * 9 * C16, tiles = L.cout / 32;
+    std::vector<_Float16> out((size_t)tiles * L.KS * 2 * NIT * 64 * 8);
+    for (int tile = 0; tile < tiles; ++tile)
+        for (int ks = 0; ks < L.KS; ++ks) {
+            int item = 0;
+            for (int j = 0; j < NSP + NSM; ++j) {
+                const bool proj = j < NSP;
+                const int s = proj ? j : j - NSP;
+                for (int c = 0; c < C16; ++c)
+                    for (int tap = 0; tap < (proj ? 1 : 9); ++tap, ++item) {
+                        const int c16 = L.KS == 2 ? ks : c;
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int m = lane & 31;
+                                const int co = 32 * tile + 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3);
+                                const int ci = 32 * s + 16 * c16 + 8 * (lane >> 5) + e;
+                                const float v = (proj ? w1[(size_t)ci * L.cout + co] : w3[((size_t)tap * L.cin + ci) * L.cout + co]) * scale;
+                                const _Float16 h = (_Float16)v;
+                                const size_t base = ((((size_t)(tile * L.KS + ks) * NIT + item) * 2) * 64 + lane) * 8 + e;
+                                out[base] = h;
+                                out[base + 64 * 8] = (_Float16)(v - (float)h);
+                            }
+                    }
+            }
+        }
+    return out;
+}
+
+float pick_scale(const std::vector<float>& a, const std::vector<float>* b) {
+    float mx = 0.0f;
+    for (float v : a) mx = std::max(mx, std::fabs(v));
+    if (b) for (float v : *b) mx = std::max(mx, std::fabs(v));
+    if (!(mx > 0.0f) || !std::isfinite(mx)) return 1.0f;
+    int e;
+    std::frexp(mx, &e);                     // mx = f * 2^e, f in [0.5, 1)
+    return std::ldexp(1.0f, 13 - e);        // mx * scale in [4096, 8192): 8x below the fp16 maximum
+}
+
+template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32>
+int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
+    constexpr int NT = 4 / PS;
+    const size_t lds = kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 : 0);
+    static bool attr = false;
+    if (!attr) {
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const int gx = std::max(1, std::min(a.batch, ncu / gy));
+    hipLaunchKernelGGL((af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32>), dim3(gx, gy), dim3(256), lds, st, a);
+    return 0;
+}
+
+}  // namespace
+
+struct f16s_net {
+    int max_batch = 0, device = 0, ncu = 256;
+    std::vector<void*> allocs;
+    float *stem_w = nullptr, *stem_b = nullptr;
+    uint4* w[10] = {};
+    float* bias[10] = {};
+    float inv_scale[10] = {};
+    // S32 activations: f0, then per block g (conv1 output) and o (block output; blocks 2 and 4 end in fp32 planes)
+    char *f0 = nullptr, *g[5] = {}, *o[5] = {};
+    int abl = 0;
+};
+
+int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::string, std::vector<float>>& V) {
+    FS_HIP_OK(hipSetDevice(device));
+    f16s_net* n = new f16s_net();
+    n->max_batch = max_batch; n->device = device;
+    FS_HIP_OK(hipDeviceGetAttribute(&n->ncu, hipDeviceAttributeMultiprocessorCount, device));
+    int rc = 0;
+    auto get = [&](const std::string& k) -> const std::vector<float>& { return V.at(k); };
+    rc = dev_upload(n->allocs, &n->stem_w, get("bone/conv1/kernel").data(), 75 * 32 * 4);
+    if (!rc) rc = dev_upload(n->allocs, &n->stem_b, get("bone/conv1/bias").data(), 32 * 4);
+    for (int b = 0; b < 5 && !rc; ++b) {
+        const std::string s = kBlockNames[b];
+        const std::vector<float>&k1 = get(s + "_conv1/kernel"), &k2 = get(s + "_conv2/kernel"), &kr = get(s + "_res/kernel");
+        const LayerCfg &L1 = kLayers[2 * b], &L2 = kLayers[2 * b + 1];
+        const float s1 = pick_scale(k1, nullptr), s2 = pick_scale(k2, &kr);
+        const std::vector<_Float16> p1 = pack_layer(L1, k1.data(), nullptr, s1), p2 = pack_layer(L2, k2.data(), kr.data(), s2);
+        rc = dev_upload(n->allocs, &n->w[2 * b], p1.data(), p1.size() * 2);
+        if (!rc) rc = dev_upload(n->allocs, &n->w[2 * b + 1], p2.data(), p2.size() * 2);
+        std::vector<float> bsum(get(s + "_conv2/bias"));
+        for (size_t i = 0; i < bsum.size(); ++i) bsum[i] += get(s + "_res/bias")[i];
+        if (!rc) rc = dev_upload(n->allocs, &n->bias[2 * b], get(s + "_conv1/bias").data(), L1.cout * 4);
+        if (!rc) rc = dev_upload(n->allocs, &n->bias[2 * b + 1], bsum.data(), L2.cout * 4);
+        n->inv_scale[2 * b] = 1.0f / s1; n->inv_scale[2 * b + 1] = 1.0f / s2;
+    }
+    auto act = [&](char** p, int ch) -> int {
+        void* q = nullptr;
+        const size_t bytes = (size_t)max_batch * (ch / 32) * kSlabB;
+        FS_HIP_OK(hipMalloc(&q, bytes));
+        FS_HIP_OK(hipMemset(q, 0, bytes));           // the zero units of S32 are never written again
+        n->allocs.push_back(q);
+        *p = (char*)q;
+        return 0;
+    };
+    if (!rc) rc = act(&n->f0, 32);
+    for (int b = 0; b < 5 && !rc; ++b) {
+        rc = act(&n->g[b], kLayers[2 * b].cout);
+        if (!rc && b != 2 && b != 4) rc = act(&n->o[b], kLayers[2 * b + 1].cout);
+    }
+    if (rc) { f16s_destroy(n); return rc; }
+    *out = n;
+    return 0;
+}
+
+void f16s_destroy(f16s_net* n) {
+    if (!n) return;
+    (void)hipSetDevice(n->device);
+    for (void* p : n->allocs) (void)hipFree(p);
+    delete n;
+}
+
+void f16s_set_ablation(f16s_net* n, int bits) { if (n) n->abl = bits; }
+
+static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, const char* in2, char* out, float* out32, int batch,
+                        int WP, int PP) {
+    F16sArgs a;
+    a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
+    a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = n->abl;
+    switch (li) {
+        case 0: return launch_cfg<1, 0, 2, 1, 2, false>(st, a, 1, n->ncu);
+        case 1: return launch_cfg<2, 1, 2, 1, 2, false>(st, a, 1, n->ncu);
+        case 2: return launch_cfg<2, 0, 4, 1, 1, false>(st, a, 1, n->ncu);
+        case 3: return launch_cfg<4, 2, 2, 2, 1, false>(st, a, 2, n->ncu);
+        case 4: return launch_cfg<4, 0, 1, 2, 2, false>(st, a, 1, n->ncu);
+        case 5: return launch_cfg<1, 4, 1, 2, 2, true>(st, a, 1, n->ncu);
+        case 6: return launch_cfg<4, 0, 2, 2, 1, false>(st, a, 1, n->ncu);
+        case 7: return launch_cfg<2, 4, 2, 2, 1, false>(st, a, 1, n->ncu);
+        case 8: return launch_cfg<2, 0, 1, 2, 2, false>(st, a, 1, n->ncu);
+        default: return launch_cfg<1, 2, 1, 2, 2, true>(st, a, 1, n->ncu);
+    }
+}
+
+int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes, int batch) {
+    if (!n || batch < 1 || batch > n->max_batch) return -1;
+    hipLaunchKernelGGL(af_stem_f16s, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
+    int rc = launch_layer(n, st, 0, n->f0, nullptr, n->g[0], nullptr, batch, 0, 0);
+    if (!rc) rc = launch_layer(n, st, 1, n->g[0], n->f0, n->o[0], nullptr, batch, 0, 0);
+    if (!rc) rc = launch_layer(n, st, 2, n->o[0], nullptr, n->g[1], nullptr, batch, 0, 0);
+    if (!rc) rc = launch_layer(n, st, 3, n->g[1], n->o[0], n->o[1], nullptr, batch, 0, 0);
+    return rc;
+}
+
+int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3, int WP, int PP) {
+    int rc = launch_layer(n, st, 4, n->o[1], nullptr, n->g[2], nullptr, batch, 0, 0);
+    if (!rc) rc = launch_layer(n, st, 5, n->g[2], n->o[1], nullptr, o3, batch, WP, PP);
+    return rc;
+}
+
+int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP, int PP) {
+    int rc = launch_layer(n, st, 6, n->o[1], nullptr, n->g[3], nullptr, batch, 0, 0);
+    if (!rc) rc = launch_layer(n, st, 7, n->g[3], n->o[1], n->o[3], nullptr, batch, 0, 0);
+    if (!rc) rc = launch_layer(n, st, 8, n->o[3], nullptr, n->g[4], nullptr, batch, 0, 0);
+    if (!rc) rc = launch_layer(n, st, 9, n->g[4], n->o[3], nullptr, o5, batch, WP, PP);
+    return rc;
+}
+
+// debug / tests: activation `which` (0 f0, 1 g1, 2 o1, 3 g2, 4 o2, 5 g3, 6 g4, 7 o4, 8 g5) of the first `batch` positions as
+// fp32 [batch][C][121] on the host (hi + lo).  Returns the channel count or < 0.
+int f16s_read_activation(f16s_net* n, int which, int batch, float* host) {
+    if (!n || batch < 1 || batch > n->max_batch) return -1;
+    const char* bufs[9] = {n->f0, n->g[0], n->o[0], n->g[1], n->o[1], n->g[2], n->g[3], n->o[3], n->g[4]};
+    const int chans[9] = {32, 64, 64, 128, 128, 32, 64, 64, 32};
+    if (which < 0 || which > 8) return -1;
+    const int C = chans[which];
+    std::vector<_Float16> h((size_t)batch * (C / 32) * kSlabB / 2);
+    FS_HIP_OK(hipDeviceSynchronize());
+    FS_HIP_OK(hipMemcpy(h.data(), bufs[which], h.size() * 2, hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int p = 0; p < kNPIX; ++p) {
+                const size_t slab = ((size_t)b * (C / 32) + c / 32) * (kSlabB / 2);
+                const size_t idx = slab + ((size_t)((c % 32) / 8) * kPIX + p + kS) * 8 + c % 8;
+                host[((size_t)b * C + c) * kNPIX + p] = (float)h[idx] + (float)h[idx + kHalfB / 2];
+            }
+    return C;
+}

@@ -658,13 +658,34 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             if (P.training) {
                 // Dirichlet(alpha) noise, tier-B generator (af_noise.h); summation order = lane partials
                 // then xor butterfly, identical to oracle afo_noise_philox_dirichlet
+                // a lane draws its KW cells in ONE rejection loop (the wave leaves it when the slowest lane has
+                // all its variates; the rounds of a cell are indexed by the counter, so the values are those
+                // of af_gamma_lt1 cell by cell)
+                {
+                    const double inv_a = 1.0 / P.alpha, one_m_a = 1.0 - P.alpha;
+                    uint32_t todo = 0;
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) { dd[k] = 0.0; todo |= ((legal[k] >> lane) & 1ull) ? (1u << k) : 0u; }
+                    uint32_t it = 0;
+                    while (todo) {
+                        const int k = __builtin_ctz(todo);
+                        double X;
+                        const int ok = af_gamma_round(P.alpha, inv_a, one_m_a,
+                                                      af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * k), it, k0, k1), &X);
+                        if (ok || it == 0xFFFFu) {
+                            X = ok ? X : 0.0;
+#pragma unroll
+                            for (int q = 0; q < KW; ++q) dd[q] = q == k ? X : dd[q];
+                            todo &= todo - 1u;
+                            it = 0;
+                        } else {
+                            ++it;
+                        }
+                    }
+                }
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    const bool lg = (legal[k] >> lane) & 1ull;
-                    dd[k] = lg ? af_gamma_lt1(P.alpha, sel_id, episode, (uint32_t)(lane + 64 * k), k0, k1) : 0.0;
-                    acc = k == 0 ? dd[0] : acc + dd[k];
-                }
+                for (int k = 0; k < KW; ++k) acc = k == 0 ? dd[0] : acc + dd[k];
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
                 const double inv = 1.0 / acc;

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "af_net.h"
+#include "af_conv_f16s.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4 floats, only 4-byte aligned
@@ -1009,6 +1010,7 @@ struct af_net {
     float *vc_w, *vc_b, *v1_w, *v1_b, *v2_w, *v2_b, *pc_w, *pc_b, *pf_w, *pf_b;
     // activations [max_batch][C][PP]
     float *f0, *g[5], *o[5];
+    f16s_net* f16s = nullptr;     // 11x11 boards: the fp16 split-operand convolution path (af_conv_f16s.hip)
 };
 
 static int pad32(int c) { return (c + 31) / 32 * 32; }
@@ -1131,6 +1133,7 @@ void af_net_destroy(af_net* n) {
     if (!n) return;
     (void)hipSetDevice(n->device);
     for (void* p : n->allocs) (void)hipFree(p);
+    f16s_destroy(n->f16s);
     for (hipStream_t s_ : n->streams) (void)hipStreamDestroy(s_);
     for (hipEvent_t e_ : n->events) (void)hipEventDestroy(e_);
     if (n->branch_stream) (void)hipStreamDestroy(n->branch_stream);
@@ -1155,6 +1158,9 @@ int af_net_finalize(af_net* n) {
     NET_HIP_OK(hipSetDevice(n->device));
     for (void* p : n->allocs) (void)hipFree(p);
     n->allocs.clear();
+    f16s_destroy(n->f16s);
+    n->f16s = nullptr;
+    if (n->S == 11 && f16s_create(&n->f16s, n->max_batch, n->device, n->vars) != 0) return AF_NET_ERR_HIP;
     auto& V = n->vars;
     int rc = AF_NET_OK;
 #define UP(dst, vec) if (!rc) rc = net_upload(n, &n->dst, (vec))
@@ -1202,6 +1208,7 @@ int af_net_finalize(af_net* n) {
 
 static int g_abl = 0;    // profiling: ablation variant of af_conv_wino<false>
 static int g_pgrid = 256; // workgroups of the persistent variant (g_wino == 4)
+static int g_f16s_abl = 0;
 static int g_wino = 1;   // 1: af_conv_wino<false> (default); 2: af_conv_wino<true> (U through LDS: measured 6 % slower); 0: direct af_conv_mfma
 
 static void launch_wino(hipStream_t st, const af_net* n, int batch, const float* in, const float* u, const float* ul, int cin,
@@ -1273,7 +1280,13 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     float* g[5];
     float* o[5];
     for (int i = 0; i < 5; ++i) { g[i] = n->g[i] + po * kBlocks[i].cout; o[i] = n->o[i] + po * kBlocks[i].cout; }
-    hipLaunchKernelGGL(af_stem_conv, dim3(batch), dim3(256), 0, st, planes, n->stem_w, n->stem_b, f0, S, WP, PP);
+    const bool split16 = g_wino == 5 && n->f16s != nullptr;
+    if (split16) {
+        f16s_set_ablation(n->f16s, g_f16s_abl);
+        if (f16s_trunk(n->f16s, st, planes, batch)) return AF_NET_ERR_HIP;
+    } else {
+        hipLaunchKernelGGL(af_stem_conv, dim3(batch), dim3(256), 0, st, planes, n->stem_w, n->stem_b, f0, S, WP, PP);
+    }
     const float* block_in[5] = {f0, o[0], o[1], o[1], o[3]};
     // the value branch (block3 + head) only depends on the trunk output o[1]: it runs on a side stream,
     // concurrently with the policy branch (blocks 4,5 + head), filling the SIMDs the 32/64-wide layers leave idle
@@ -1281,7 +1294,7 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     if (g_branch && n->branch_stream) {
         vs = n->branch_stream;
     }
-    for (int i = 0; i < 5; ++i) {
+    for (int i = split16 ? 2 : 0; i < 5; ++i) {
         const Block& b = kBlocks[i];
         hipStream_t st_main = st;
         if (i == 2 && vs != st_main) {
@@ -1289,7 +1302,10 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
             NET_HIP_OK(hipStreamWaitEvent(vs, n->ev_trunk, 0));
         }
         hipStream_t st = (i == 2) ? vs : st_main;
-        if (g_wino) {
+        if (split16) {
+            if (i == 2 && f16s_value_branch(n->f16s, st, batch, o[2], WP, PP)) return AF_NET_ERR_HIP;
+            if (i == 4 && f16s_policy_branch(n->f16s, st, batch, o[4], WP, PP)) return AF_NET_ERR_HIP;
+        } else if (g_wino) {
             // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
             launch_wino(st, n, batch, block_in[i], n->wino1_u[i], n->wino1_ul[i], b.cin, nullptr, nullptr, 0,
                         n->conv1_b[i], g[i], b.cout);
@@ -1376,9 +1392,16 @@ int af_net_tune(int32_t cout_pad, int32_t shape) {
     if (cout_pad == 5) { g_phead = shape; return AF_NET_OK; }                       // 5: MFMA policy head (1/0)
     if (cout_pad == 4) { g_branch = shape; return AF_NET_OK; }                      // 4: value branch on a side stream (1/0)
     if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)
+    if (cout_pad == 7) { g_f16s_abl = shape; return AF_NET_OK; }                      // 7: ablation bits of af_conv_f16s (profiling)
     if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
     if (cout_pad == 2) { g_subbatch = shape; return AF_NET_OK; }                     // 2: sub-batch size (0 = batch/streams)
     return AF_NET_ERR_ARG;
+}
+
+int af_net_debug_activation(af_net* n, int32_t which, int32_t batch, float* host_out) {
+    if (!n || !host_out || !n->f16s) return AF_NET_ERR_ARG;
+    const int c = f16s_read_activation(n->f16s, which, batch, host_out);
+    return c < 0 ? AF_NET_ERR_ARG : c;
 }
 
 int64_t af_net_flops_per_position(const af_net* n) {

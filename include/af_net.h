@@ -43,13 +43,19 @@ int af_net_finalize(af_net* n);
 int af_net_forward(af_net* n, void* stream, const float* planes_dev, int32_t batch, float* policy_dev, float* value_dev);
 
 /* Benchmark / A-B knobs (process-global):
- *   key 0: conv path — 1 Winograd register ring (default), 2 Winograd with U shared through LDS, 3 Winograd with both
- *          operands staged by LDS-DMA, 4 Winograd on a persistent grid, 0 direct implicit GEMM
+ *   key 0: conv path — 5 fp16 split-operand implicit GEMM (af_conv_f16s.hip; 11x11 boards), 1 fp32 Winograd register
+ *          ring, 2 Winograd with U shared through LDS, 3 Winograd with both operands staged by LDS-DMA, 4 Winograd on a
+ *          persistent grid, 0 fp32 direct implicit GEMM
  *   key 1: number of sub-batch side streams (default 1)      key 2: sub-batch size (0 = batch / streams)
  *   key 3: ablation variant of the Winograd kernel (profiling only; results are wrong by design)
  *   key 4: value branch on a side stream (default 1)         key 5: MFMA policy head (default 1)
- *   key 6: workgroups of the persistent variant (default 256) */
+ *   key 6: workgroups of the persistent variant (default 256)   key 7: ablation bits of path 5 (profiling) */
 int af_net_tune(int32_t key, int32_t value);
+
+/* Tests / debugging of the fp16 split-operand path (conv path 5, 11x11 boards): intermediate activation `which`
+ * (0 stem, 1/2 block1 conv1/output, 3/4 block2, 5 block3 conv1, 6/7 block4, 8 block5 conv1) of the first `batch`
+ * positions of the last forward, as fp32 [batch][C][121] on the host.  Returns the channel count C or <0. */
+int af_net_debug_activation(af_net* n, int32_t which, int32_t batch, float* host_out);
 
 /* FLOPs (2*MAC) of one position's forward pass, as executed (direct convolution). */
 int64_t af_net_flops_per_position(const af_net* n);

@@ -139,25 +139,33 @@ AF_HD float af_powf(float x, float y) {
 
 /* ---- samplers ---- */
 
-/* One Gamma(alpha,1) variate, alpha < 1: numpy legacy_standard_gamma's
- * rejection loop (restated in SURVEY.md §8a), uniforms taken from
- * Philox(counter = (sel, episode, GAMMA<<24|cell, round)). */
+/* One round of numpy legacy_standard_gamma's rejection loop for alpha < 1 (restated in
+ * SURVEY.md §8a): U, V = Exp(1) from the four words r; returns 1 and *x when the candidate is
+ * accepted.  Written without data-dependent branches so that a 64-lane wavefront runs every
+ * round in lockstep: both arms share one pow, the second arm's log is evaluated for all
+ * (its argument (1-U)/alpha is >= 1 in the first arm) and V + 0.0 == V in the first arm. */
+AF_HD int af_gamma_round(double alpha, double inv_a, double one_m_a, af_u32x4 r, double* x) {
+    const double U = af_u53(r.v[0], r.v[1]);
+    const double V = -af_log(1.0 - af_u53(r.v[2], r.v[3]));
+    const double Yl = -af_log((1.0 - U) / alpha);
+    const int first = U <= one_m_a;
+    const double Y = first ? 0.0 : Yl;
+    const double base = first ? U : one_m_a + alpha * Yl;
+    const double X = af_pow(base, inv_a);
+    *x = X;
+    return X <= V + Y;
+}
+
+/* One Gamma(alpha,1) variate, alpha < 1: rounds it = 0,1,... until one accepts; uniforms taken
+ * from Philox(counter = (sel, episode, GAMMA<<24|cell, round)). */
 AF_HD double af_gamma_lt1(double alpha, uint32_t sel, uint32_t episode, uint32_t cell,
                           uint32_t k0, uint32_t k1) {
     const double inv_a = 1.0 / alpha;
     const double one_m_a = 1.0 - alpha;
     for (uint32_t it = 0;; ++it) {
-        af_u32x4 r = af_philox4x32(sel, episode, (AF_STREAM_GAMMA << 24) | cell, it, k0, k1);
-        double U = af_u53(r.v[0], r.v[1]);
-        double V = -af_log(1.0 - af_u53(r.v[2], r.v[3]));
-        if (U <= one_m_a) {
-            double X = af_pow(U, inv_a);
-            if (X <= V) return X;
-        } else {
-            double Y = -af_log((1.0 - U) / alpha);
-            double X = af_pow(one_m_a + alpha * Y, inv_a);
-            if (X <= V + Y) return X;
-        }
+        double X;
+        if (af_gamma_round(alpha, inv_a, one_m_a,
+                           af_philox4x32(sel, episode, (AF_STREAM_GAMMA << 24) | cell, it, k0, k1), &X)) return X;
         if (it == 0xFFFFu) return 0.0;   /* unreachable in practice; bounds the loop */
     }
 }
