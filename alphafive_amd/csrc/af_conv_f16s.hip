@@ -47,9 +47,14 @@ constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;
 constexpr uint32_t kRowB = kPIX * 16u;          // one unit row: 8 channels x 144 units
 constexpr uint32_t kHalfB = 4u * kRowB;         // the hi (or lo) halves of a 32-channel slab
 constexpr uint32_t kSlabB = 2u * kHalfB;        // 18,432 bytes
-constexpr int kPieces = kSlabB / 1024;          // 18 LDS-DMA wave-instructions per slab
+constexpr int kPieces = 16;                     // LDS-DMA wave-instructions (1 KB) per slab: units 8..135 of each of the 8 unit rows
 constexpr uint32_t kLds0 = 256u;                // slack so that unit -1 of a slot stays inside LDS
-constexpr uint32_t kZoff = kLds0 + 2u * kSlabB; // all-zero region (edge lanes)
+#ifndef AF_F16S_DIST
+#define AF_F16S_DIST 3
+#endif
+constexpr int kDist = AF_F16S_DIST;             // prefetch distance in slabs: slab t multiplies while t+1 .. t+kDist land
+constexpr int kRing = kDist + 1;                // LDS slots
+constexpr uint32_t kZoff = kLds0 + kRing * kSlabB; // all-zero region (edge lanes)
 constexpr uint32_t kBiasOff = kZoff + kSlabB;   // 128 floats
 constexpr uint32_t kScrOff = kBiasOff + 512u;   // k-split exchange
 
@@ -71,11 +76,11 @@ struct F16sArgs {
     float* out32;         // OUT32: fp32 [position][COUT][PP] padded planes (the head kernels' input)
     float inv_scale;      // 1 / weight scale
     int batch, WP, PP;
-    int abl;              // profiling: bit 0 no LDS-DMA after the first slab, bit 1 no stores
+    int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
 };
 
 template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32>
-__global__ __launch_bounds__(256, 1) void af_conv_f16s(F16sArgs A) {
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_conv_f16s(F16sArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 4 / PS;                    // pixel tiles per wave
     constexpr int C16 = 2 / KS;                   // 16-channel k-steps per slab and wave
@@ -96,17 +101,34 @@ __global__ __launch_bounds__(256, 1) void af_conv_f16s(F16sArgs A) {
     auto slab_src = [&](int p, int j) -> const char* {
         return j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabB : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabB;
     };
-    auto dma_piece = [&](const char* src, uint32_t slot_off, int q) {       // piece wv + 4q of a slab
+    // piece wv + 4q of a slab, q = 0..3: every wave issues exactly 4 LDS-DMA instructions per slab, so that
+    // "s_waitcnt vmcnt(4 * (kDist - 1))" means "everything but the kDist - 1 slabs requested last has landed".  A piece
+    // is 64 units of one unit row: units 8..71 or 72..135 (pixels sit at units 11..131; the other units of a slot are
+    // zeroed once and never written).
+    auto dma_piece = [&](const char* src, uint32_t slot_off, int q) {
         const int piece = wv + 4 * q;
-        if (piece < kPieces)
-            glds16(src + piece * 1024 + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + piece * 1024u)));
+        const uint32_t off = (uint32_t)(piece >> 3) * kHalfB + (uint32_t)((piece >> 1) & 3) * kRowB + (8u + 64u * (piece & 1)) * 16u;
+        glds16(src + off + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + off)));
     };
+    // slab number `idx` of the stream this workgroup consumes (positions pos0, pos0 + gridDim.x, ...; SPP slabs each)
+    const int pos0 = pos;
+    auto stream_src = [&](uint32_t idx) -> const char* {
+        const int p = pos0 + (int)(idx / SPP) * (int)gridDim.x, j = (int)(idx % SPP);
+        return slab_src(p, j);
+    };
+    const uint32_t nslabs = (uint32_t)((A.batch - pos0 + (int)gridDim.x - 1) / (int)gridDim.x) * SPP;
 
-    for (uint32_t u = threadIdx.x; u < kSlabB / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
-    if (threadIdx.x < kLds0 / 16) *reinterpret_cast<uint4*>(smem + threadIdx.x * 16) = uint4{0, 0, 0, 0};   // the slack below slot 0
+    // slack, ring slots (their pad units stay zero for the whole launch) and the zero region
+    for (uint32_t u = threadIdx.x; u < (kZoff + kSlabB) / 16; u += 256) *reinterpret_cast<uint4*>(smem + u * 16) = uint4{0, 0, 0, 0};
+    __syncthreads();
     if (threadIdx.x < CT * 32) reinterpret_cast<float*>(smem + kBiasOff)[threadIdx.x] = A.bias[(int)blockIdx.y * CT * 32 + threadIdx.x];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) dma_piece(slab_src(pos, 0), 0u, q);
+    for (int d = 0; d < kDist; ++d) {
+        if ((uint32_t)d < nslabs) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma_piece(stream_src(d), (uint32_t)d * kSlabB, q);
+        }
+    }
 
     // resident weights: 2 * NIT fragments
     h8 W[2 * NIT];
@@ -140,9 +162,8 @@ __global__ __launch_bounds__(256, 1) void af_conv_f16s(F16sArgs A) {
     __builtin_amdgcn_s_barrier();
 
     uint32_t t = 0;
+    uint32_t cur = 0u, nxd = (uint32_t)kDist * kSlabB;        // ring slots of slab t and of slab t + kDist
     for (; pos < A.batch; pos += gridDim.x) {
-        const int nxt = pos + (int)gridDim.x;
-        const bool more_pos = nxt < A.batch;
         f32x16 acc[NT];
 #pragma unroll
         for (int jj = 0; jj < NT; ++jj)
@@ -154,9 +175,8 @@ __global__ __launch_bounds__(256, 1) void af_conv_f16s(F16sArgs A) {
             const bool proj = j < NSP;
             const int NI = proj ? ITP : ITM;
             const int ibase = proj ? j * ITP : NSP * ITP + (j - NSP) * ITM;
-            const uint32_t cur = (t & 1u) ? kSlabB : 0u, nx = kSlabB - cur;
-            const bool more = ((j + 1 < SPP) || more_pos) && !(A.abl & 1);
-            const char* nsrc = (j + 1 < SPP) ? slab_src(pos, j + 1) : slab_src(nxt, 0);
+            const bool more = t + kDist < nslabs && !(A.abl & 1);
+            const char* nsrc = stream_src((A.abl & 4) ? (t % SPP) : (more ? t + kDist : t));   // abl bit 2: re-request the first position's slabs (L2-hot)
             uint32_t bC[NT], bL[NT], bR[NT];
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
@@ -164,21 +184,28 @@ __global__ __launch_bounds__(256, 1) void af_conv_f16s(F16sArgs A) {
                 bL[jj] = edgeL[jj] ? zb[jj] : bC[jj];
                 bR[jj] = edgeR[jj] ? zb[jj] : bC[jj];
             }
-            auto rd = [&](int it, int jj, int p) -> h8 {
+            // B fragment of item `it` (k-step c, tap), half p, for the pixel tile whose centre / left / right bases are given
+            auto rd = [proj](const char* sm, int it, int p, uint32_t c_, uint32_t l_, uint32_t r_) -> h8 {
                 const int c = proj ? it : it / 9, tap = proj ? 4 : it % 9, ky = tap / 3, kx = tap % 3;
-                const uint32_t base = kx == 0 ? bL[jj] : (kx == 2 ? bR[jj] : bC[jj]);
+                const uint32_t base = kx == 0 ? l_ : (kx == 2 ? r_ : c_);
                 const uint32_t imm = (uint32_t)p * kHalfB + (KS == 1 ? 2u * c * kRowB : 0u) + (uint32_t)(ky * kS + kx) * 16u;
-                return *reinterpret_cast<const h8*>(smem + base + imm);
+                return *reinterpret_cast<const h8*>(sm + base + imm);
             };
             h8 fr[2][NT][2];
 #pragma unroll
-            for (int jj = 0; jj < NT; ++jj) { fr[0][jj][0] = rd(0, jj, 0); fr[0][jj][1] = rd(0, jj, 1); }
+            for (int jj = 0; jj < NT; ++jj) {
+                fr[0][jj][0] = rd(smem, 0, 0, bC[jj], bL[jj], bR[jj]);
+                fr[0][jj][1] = rd(smem, 0, 1, bC[jj], bL[jj], bR[jj]);
+            }
 #pragma clang loop unroll(full)
             for (int it = 0; it < NI; ++it) {
                 const int b = it & 1;
                 if (it + 1 < NI) {
 #pragma unroll
-                    for (int jj = 0; jj < NT; ++jj) { fr[b ^ 1][jj][0] = rd(it + 1, jj, 0); fr[b ^ 1][jj][1] = rd(it + 1, jj, 1); }
+                    for (int jj = 0; jj < NT; ++jj) {
+                        fr[b ^ 1][jj][0] = rd(smem, it + 1, 0, bC[jj], bL[jj], bR[jj]);
+                        fr[b ^ 1][jj][1] = rd(smem, it + 1, 1, bC[jj], bL[jj], bR[jj]);
+                    }
                 }
                 const h8 wh = W[2 * (ibase + it)], wl = W[2 * (ibase + it) + 1];
 #pragma unroll
@@ -197,15 +224,20 @@ __global__ __launch_bounds__(256, 1) void af_conv_f16s(F16sArgs A) {
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
                 }
-                if (it < 5 && more) dma_piece(nsrc, nx, it);               // the next slab: one 1 KB piece per item
+                if (it < 4 && more) dma_piece(nsrc, nxd, it);              // slab t + kDist: one 1 KB piece per item
             }
             if (more) {
 #pragma unroll
-                for (int q = NI; q < 5; ++q) dma_piece(nsrc, nx, q);
+                for (int q = NI; q < 4; ++q) dma_piece(nsrc, nxd, q);
+                // slab t+1 has landed: only the pieces of the kDist - 1 slabs requested after it may be in flight
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 1)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next slab has landed ...
-            __builtin_amdgcn_s_barrier();                                    // ... for every wave, and all are done with this one
+            __builtin_amdgcn_s_barrier();                                    // ... for every wave, and all are done with slab t
             ++t;
+            cur = cur + kSlabB == kRing * kSlabB ? 0u : cur + kSlabB;
+            nxd = nxd + kSlabB == kRing * kSlabB ? 0u : nxd + kSlabB;
         }
 
         // k-split: the two waves of a pair exchange the halves they do not finish

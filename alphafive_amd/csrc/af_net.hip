@@ -1209,7 +1209,7 @@ int af_net_finalize(af_net* n) {
 static int g_abl = 0;    // profiling: ablation variant of af_conv_wino<false>
 static int g_pgrid = 256; // workgroups of the persistent variant (g_wino == 4)
 static int g_f16s_abl = 0;
-static int g_wino = 1;   // 1: af_conv_wino<false> (default); 2: af_conv_wino<true> (U through LDS: measured 6 % slower); 0: direct af_conv_mfma
+static int g_wino = 5;   // 5: fp16 split-operand implicit GEMM on 11x11 boards (default; other sizes fall through to 1); 1: af_conv_wino<false>; 2: af_conv_wino<true> (U through LDS: measured 6 % slower); 0: direct af_conv_mfma
 
 static void launch_wino(hipStream_t st, const af_net* n, int batch, const float* in, const float* u, const float* ul, int cin,
                         const float* in2, const float* u2, int cin2, const float* bias, float* out, int cout) {

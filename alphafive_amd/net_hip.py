@@ -1,4 +1,4 @@
-"""ctypes binding of libaf_net.so (include/af_net.h): the hand-written fp32-MFMA forward pass.
+"""ctypes binding of libaf_net.so (include/af_net.h): the hand-written MFMA forward pass.
 Used by ResNet.select_backend("hip"/"auto"); raises if the library is missing (no fallback here —
 the caller decides whether the torch-op path is acceptable)."""
 import ctypes as C
@@ -119,16 +119,34 @@ def make_eval(resnet):
     return pv
 
 
-def roofline_info():
+# 3x3 + folded 1x1 convolution MACs per pixel of the five residual blocks (network.py:52-88): the part of the forward
+# pass that runs on af_conv_f16s, each MAC issued as three fp16 MFMA MACs (hi*hi, hi*lo, lo*hi)
+_SPLIT_MAC_PER_PIXEL = sum(9 * ci * co + 9 * co * co + ci * co for ci, co in ((32, 64), (64, 128), (128, 32), (128, 64), (64, 32)))
+# HBM bytes per position of that path (S32 activations, 18,432 B per 32-channel slab; weights stay in registers):
+# slabs read (3x3 input + block input of the projection; block2's conv2 reads its position from two workgroups, the
+# second read is an L2 hit) + slabs written + the two fp32 head inputs + the input planes
+_SPLIT_BYTES_PER_POSITION = (36 * 16384 + 18 * 15488 + 2 * 32 * 121 * 4 + 3 * 121 * 4)
+
+
+def roofline_info(board_size=11):
+    if board_size == 11:
+        return {"backend": "hip (af_conv_f16s.hip: fp16 split-operand implicit-GEMM convs on v_mfma_f32_32x32x16_f16, "
+                           "fp32 accumulate, weight-stationary, LDS-DMA slab ring; stem / heads from af_net.hip)",
+                "kernel": "af_net_forward = af_stem_f16s + 10x af_conv_f16s + af_value_head + af_policy_head_mfma "
+                          "(whole forward timed; af_conv_f16s carries 99 % of the algorithmic FLOPs, each MAC issued as "
+                          "3 fp16 MFMA MACs)",
+                "peak_tflops": 2500.0, "issued_flop_per_position": 2 * 3 * _SPLIT_MAC_PER_PIXEL * 121,
+                "algorithmic_bytes_per_position": _SPLIT_BYTES_PER_POSITION}
     return {"backend": "hip (af_net.hip: fp32 MFMA Winograd F(2x2,3x3) convs, fused transforms/bias/ELU/residual)",
             "kernel": "af_net_forward = af_stem_conv + 10x af_conv_wino + af_value_head + af_policy_head "
                       "(whole forward timed; af_conv_wino carries 97 % of the algorithmic FLOPs; achieved = "
-                      "direct-convolution FLOPs / time, the MFMAs issued are 2.25x fewer on the 3x3 layers)"}
+                      "direct-convolution FLOPs / time, the MFMAs issued are 2.25x fewer on the 3x3 layers)",
+            "peak_tflops": 157.3}
 
 
 def tune(key, value):
-    """Benchmark knob (af_net_tune): key 32/64/128 = tile shape of the direct kernel for that width;
-    key 0 = conv path (2 Winograd + LDS-shared U, 1 Winograd, 0 direct); key 1/2 = sub-batch streams/size;
-    key 3 = ablation variant of the Winograd kernel (profiling only)."""
+    """Benchmark knob (af_net_tune, include/af_net.h): key 0 = conv path (5 fp16 split-operand implicit GEMM = default
+    on 11x11, 1 fp32 Winograd, 2 Winograd + LDS-shared U, 3 / 4 Winograd variants, 0 fp32 direct); key 1/2 = sub-batch
+    streams/size; key 3 / 7 = ablation variants (profiling only)."""
     lib().af_net_tune.argtypes = [C.c_int32, C.c_int32]
     _check(lib().af_net_tune(key, value), "af_net_tune")

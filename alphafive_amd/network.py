@@ -148,21 +148,21 @@ class ResNet(object):
         return p.cpu().numpy(), v.cpu().numpy()
 
     # ---- backend selection for the batched engine
-    def select_backend(self, name="auto"):
-        """-> callable planes[B,3,S,S] -> (prob, value) on device.  "torch": PyTorch-ROCm ops
-        (MIOpen convs / hipBLASLt GEMMs).  "hip": the hand-written fused MFMA kernel when built
-        for this board size.  "auto": hip if available, else torch."""
-        if name in ("auto", "hip"):
-            try:
-                from . import net_hip
-                fn = net_hip.make_eval(self)
-                if fn is not None:
-                    self._backend = "hip"
-                    return fn
-            except ImportError:
-                pass
-            if name == "hip":
-                raise RuntimeError("HIP net kernel not available for this configuration")
+    def select_backend(self, name="hip"):
+        """-> callable planes[B,3,S,S] -> (prob, value) on device.  "hip" (default): the hand-written MFMA kernels
+        (libaf_net.so) — raises when the library is missing or the configuration is not covered, there is no silent
+        fallback.  "torch": PyTorch-ROCm ops (MIOpen convs / hipBLASLt GEMMs), kept as the plain reference."""
+        if name == "auto":                       # historical name: now means the product path, strictly
+            name = "hip"
+        if name == "hip":
+            from . import net_hip
+            fn = net_hip.make_eval(self)         # ImportError if libaf_net.so is not built
+            if fn is None:
+                raise RuntimeError("HIP net kernels need a cuda device and a board size of 3..15")
+            self._backend = "hip"
+            return fn
+        if name != "torch":
+            raise ValueError("unknown net backend %r" % (name,))
         self._backend = "torch"
         return self.eval_device
 
@@ -177,8 +177,8 @@ class ResNet(object):
     def roofline_info(self, pv=None):
         if getattr(self, "_backend", "torch") == "hip":
             from . import net_hip
-            return net_hip.roofline_info()
-        return {"backend": "torch-rocm (MIOpen convs + hipBLASLt GEMMs)",
+            return net_hip.roofline_info(self.board_size)
+        return {"backend": "torch-rocm (MIOpen convs + hipBLASLt GEMMs)", "peak_tflops": 157.3,
                 "kernel": "net forward = 18 MIOpen conv launches + 3 GEMMs + elementwise (whole forward timed)"}
 
     # ---- network.py:124-134

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — self-play moves/sec (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 4 --warmup 1
+    python bench.py                              # = --gpus 1 --steps 20 --warmup 8
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,8 +13,10 @@ episodes are gathered to rank 0 over RCCL at step boundaries.
 
 A "step" = one pass of the hot path over the batch that commits one move per game on
 average: the rank ticks (tree kernel -> leaf batch -> net) until its games have committed
-G more plies (~460-500 ticks).  value = plies committed by all ranks in the timed region /
-max-over-ranks wall time.  Inputs are synthetic (all games start from the empty board) and
+G more plies (~400-500 ticks).  value = plies committed by all ranks in the timed region /
+max-over-ranks wall time.  The metric is a STEADY-STATE rate: the defaults warm up for
+8 plies per game and time 20 more, so finished episodes, store collection and game restarts are
+inside the timed region; a run in which no episode finished is reported with "value": null.  Inputs are synthetic (all games start from the empty board) and
 resident in HBM; nothing crosses PCIe on the tick path.
 """
 import argparse
@@ -151,8 +153,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=500)
     ap.add_argument("--upper", type=int, default=642)
@@ -160,8 +162,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--net", default="auto", choices=["auto", "torch", "hip", "deep-bf16", "deep-bf16-torch"],
-                    help="deep-bf16 = BASELINE configs[4]: 8-block width-128 net in bf16 (use with --games 8192)")
+    ap.add_argument("--net", default="hip", choices=["hip", "torch", "deep-bf16", "deep-bf16-torch"],
+                    help="hip (default): the hand-written kernels, fails without libaf_net.so; torch: PyTorch-ROCm ops "
+                         "(reference only); deep-bf16 = BASELINE configs[4]: 8-block width-128 net in bf16 (use with --games 8192)")
     args = ap.parse_args()
     if args.cpu_worker > 0:
         return _cpu_worker(args)
@@ -279,6 +282,10 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_plies, t = float(tot.item()), float(tmax.item())
+    eps_all = torch.tensor([float(ct1["episodes"] - ct0["episodes"])], device=comm_dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(eps_all, op=dist.ReduceOp.SUM)
+    steady = eps_all.item() > 0
 
     if rank == 0:
         d = {k: ct1[k] - ct0[k] for k in ct1}
@@ -286,24 +293,24 @@ def main():
         tick_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_tick]))
         net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net]))
         flop_pos = FLOP_PER_POSITION if cfg.board_size == 11 else net.flops_per_position()
-        peak, dtype_name = PEAK_FP32_MFMA_TFLOPS, "f32"
+        roof = net.roofline_info(pv)
+        peak, dtype_name = roof.get("peak_tflops", PEAK_FP32_MFMA_TFLOPS), "f32"
         if deep is not None:
             flop_pos, peak, dtype_name = deep.flops_per_position(), 2500.0, "bf16"   # dense bf16 MFMA peak
         net_tflops = G * flop_pos / (net_ms * 1e-3) / 1e12
         tree_gbs = tree_bytes(d, C) / n_ticks / (tick_ms * 1e-3) / 1e9
-        roof = net.roofline_info(pv)
         # HBM traffic per launch: NOT measured live (PMC collection needs its own rocprofv3 passes); taken from the
-        # committed counter profile when this run is the profiled workload, else null
+        # committed counter profile of THIS round's kernels when this run is the profiled workload, else null
         traffic_net = traffic_tick = None
         traffic_src = None
-        tp = os.path.join(REPO, "profiles", "r1_14_pmc_hbm_traffic.json")
+        tp = os.path.join(REPO, "profiles", "r2_pmc_hbm_traffic.json")
         if os.path.exists(tp) and deep is None and roof["backend"].startswith("hip"):
             with open(tp) as f:
                 prof = json.load(f)
             if prof["workload"] == {"games": G, "board_size": cfg.board_size}:
                 traffic_net = prof["net_forward_bytes_per_launch"]["corrected"]
                 traffic_tick = prof["tick_kernel_bytes_per_launch"]["corrected"]
-                traffic_src = "profiles/r1_14_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                traffic_src = "profiles/r2_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         if deep is not None:
             roof = ({"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
                      "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"} if args.net.endswith("torch") else
@@ -311,11 +318,16 @@ def main():
                      "kernel": "deep net forward = af_tower_stem + 16x af_tower_conv + af_tower_heads + 3 dense layers (whole forward timed; af_tower_conv carries 99 % of the FLOPs)"})
         copy_gbs = copy_bandwidth_gbs(dev)
         out = {
-            "metric": "self-play moves/sec (%dx%d, %d sims/move)" % (cfg.board_size, cfg.board_size, args.sims), "value": total_plies / t, "unit": "moves/s",
+            "metric": "self-play moves/sec (%dx%d, %d sims/move)" % (cfg.board_size, cfg.board_size, args.sims),
+            "value": (total_plies / t) if steady else None, "unit": "moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1]: {G} concurrent 11x11 games per GPU, {args.sims} sims/move "
-                                    f"(cap {args.upper}), training-mode MCTS, alphaFive-6960 net fp32, batched leaf eval")
+            "config": {"workload": (f"BASELINE configs[4]: {G} concurrent 11x11 games per GPU, {args.sims} sims/move (cap {args.upper}), "
+                                    f"training-mode MCTS, 8-block x 128 residual net in bf16 (random init), batched leaf eval")
+                       if deep is not None else
+                       (f"BASELINE configs[1]: {G} concurrent 11x11 games per GPU, {args.sims} sims/move "
+                        f"(cap {args.upper}), training-mode MCTS, alphaFive-6960 net (fp32-class: fp16 split operands, "
+                        f"fp32 accumulate; within 1e-5 of the fp64 restatement), batched leaf eval")
                        if cfg.board_size == 11 else
                        (f"BASELINE configs[3]-style: {G} concurrent {cfg.board_size}x{cfg.board_size} games per GPU, "
                         f"{args.sims} sims/move (cap {args.upper}), random-init net of the same architecture, fp32"),
@@ -324,11 +336,13 @@ def main():
                        "sims_per_ply_rank0": d["sims"] / max(1, d["plies"]),
                        "selects_per_sim": d["selects"] / max(1, d["sims"]),
                        "terminal_frac": d["terminals"] / max(1, d["sims"]),
-                       "episodes_gathered": gathered["episodes"]},
+                       "episodes_gathered": gathered["episodes"], "episodes_finished_in_timed_region": int(eps_all.item())},
             "roofline": {"kernel": roof["kernel"], "bound": "mfma", "achieved": net_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "traffic": traffic_net, "traffic_source": traffic_src, "ms_per_launch": net_ms,
-                         "flop_per_launch": G * flop_pos},
+                         "flop_per_launch": G * flop_pos,
+                         "note": "achieved = algorithmic (direct-convolution) FLOPs per launch / launch time; peak = dense MFMA peak of the "
+                                 "operand type the kernel issues (fp16: 2.5 PFLOP/s; fp32: 157.3 TFLOP/s)"},
             "tree_roofline": {"kernel": "af_tick_kernel<%d>" % (2 if C <= 128 else 4), "bound": "hbm", "achieved": tree_gbs,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": tree_gbs / PEAK_HBM_GBS, "traffic": traffic_tick,
                               "ms_per_launch": tick_ms, "bytes_per_launch": tree_bytes(d, C) / n_ticks,
@@ -342,6 +356,18 @@ def main():
                            "collector_runs": d["collector_runs"], "collector_slots_scanned": d["collector_scanned"],
                            "yields": d["yields"], "stalls": d["stalls"]},
         }
+        if "issued_flop_per_position" in roof and deep is None:
+            issued = G * roof["issued_flop_per_position"] / (net_ms * 1e-3) / 1e12
+            out["roofline"]["mfma_issued_tflops"] = issued          # MFMA FLOPs actually issued (3 per algorithmic MAC)
+            out["roofline"]["mfma_issued_frac"] = issued / peak
+            hb = G * roof["algorithmic_bytes_per_position"]
+            out["roofline"]["hbm_algorithmic_bytes_per_launch"] = hb
+            out["roofline"]["hbm_algorithmic_gbs"] = hb / (net_ms * 1e-3) / 1e9
+            out["roofline"]["hbm_frac_of_peak"] = hb / (net_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+        if not steady:
+            out["invalid"] = ("no episode finished inside the run: this is an opening-phase rate, not the steady-state metric "
+                              "(SURVEY 8d); use the defaults (--warmup 8 --steps 20)")
+            out["opening_phase_moves_per_s"] = total_plies / t
         if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, weights if cfg.board_size == 11 else None)
             out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, weights if cfg.board_size == 11 else None)

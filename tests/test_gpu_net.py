@@ -82,8 +82,8 @@ def test_flop_count_matches_survey():
 
 
 def test_alternate_conv_paths_agree_with_fp64():
-    """The direct implicit-GEMM path (af_net_tune(0,0)), the LDS-shared-U Winograd path (0,2) and the LDS-DMA
-    Winograd path (0,3) stay correct."""
+    """The fp32 paths behind af_net_tune(0, .) — direct implicit GEMM (0), Winograd register ring (1), LDS-shared U (2),
+    LDS-DMA (3), persistent grid (4) — and the default fp16 split-operand path (5) all stay within the bar."""
     import torch
     from alphafive_amd import net_hip
     from alphafive_amd.network import ResNet
@@ -94,13 +94,13 @@ def test_alternate_conv_paths_agree_with_fp64():
     xt = torch.from_numpy(x).cuda()
     p64, v64 = net_fp64.forward(net.variables, x[:32])
     try:
-        for mode in (0, 2, 3, 4, 1):
+        for mode in (0, 2, 3, 4, 1, 5):
             net_hip.tune(0, mode)
             p, v = pv(xt)
             assert np.abs(v[:32].cpu().numpy() - v64).max() < 1e-5, mode
             assert np.abs(p[:32].cpu().numpy() - p64).max() < 1e-5, mode
     finally:
-        net_hip.tune(0, 1)
+        net_hip.tune(0, 5)
 
 
 def test_hip_evaluator_follows_weight_updates():

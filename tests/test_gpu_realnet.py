@@ -74,7 +74,7 @@ def test_selfplay_engine_with_real_net_produces_valid_episodes():
     net = ResNet(11, device="cuda")
     net.load_npz(W)
     cfg = make_cfg(simulation_per_step=40, upper_simulation_per_step=60)
-    sp = SelfPlayEngine(cfg, 256, net.select_backend("auto"), device=0, seed=9)
+    sp = SelfPlayEngine(cfg, 256, net.select_backend("hip"), device=0, seed=9)
     eps = []
     for _ in range(60):
         sp.run_ticks(100)

@@ -79,7 +79,7 @@ for mode in (1, 5):
     print("mode %d: %.3f ms per forward of %d positions" % (mode, e0.elapsed_time(e1) / 20, B), flush=True)
 if os.environ.get("ABL"):
     net_hip.tune(0, 5)
-    for bits in (1, 2, 3):
+    for bits in (1, 2, 3, 4, 6):
         net_hip.tune(7, bits)
         for _ in range(2):
             hn(xb)
