@@ -13,7 +13,7 @@
 // (rows back to back, 11 zero units above, 12 below; the zeros are never written).  A 32-channel slab is 18,432
 // contiguous bytes.
 //
-// Kernel af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32>: NSM 32-channel slabs of the 3x3 input, NSP slabs of the block input
+// Kernel af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC>: NSM 32-channel slabs of the 3x3 input, NSP slabs of the block input
 // whose 1x1 projection is folded in as extra k-steps.  Weight-stationary and persistent: a workgroup = 4 waves (one per
 // SIMD, 512 registers) = CT cout tiles of 32 x KS halves of every 32-channel slab (k-split: wave ks takes channels
 // 16ks..16ks+15) x PS pixel groups (4/PS tiles of 32 pixels); each wave keeps ALL its weight fragments (hi and lo) in
@@ -79,7 +79,7 @@ struct F16sArgs {
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
 };
 
-template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32>
+template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_conv_f16s(F16sArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 4 / PS;                    // pixel tiles per wave
@@ -164,11 +164,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     uint32_t t = 0;
     uint32_t cur = 0u, nxd = (uint32_t)kDist * kSlabB;        // ring slots of slab t and of slab t + kDist
     for (; pos < A.batch; pos += gridDim.x) {
-        f32x16 acc[NT];
+        // XACC: the cross terms (W_hi*X_lo, W_lo*X_hi; 2^-11 of the main term) get their own accumulator, so the main
+        // accumulator is rounded once per item instead of three times (the MFMA's fp32 accumulation is where this path
+        // loses accuracy); used where the register budget allows it
+        f32x16 acc[NT], acx[XACC ? NT : 1];
 #pragma unroll
         for (int jj = 0; jj < NT; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[jj][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) { acc[jj][r] = 0.0f; if (XACC) acx[jj][r] = 0.0f; }
 
 #pragma clang loop unroll(full)
         for (int j = 0; j < SPP; ++j) {
@@ -210,10 +213,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 const h8 wh = W[2 * (ibase + it)], wl = W[2 * (ibase + it) + 1];
 #pragma unroll
                 for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fr[b][jj][0], acc[jj], 0, 0, 0);
+                if (XACC) {
 #pragma unroll
-                for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fr[b][jj][1], acc[jj], 0, 0, 0);
+                    for (int jj = 0; jj < NT; ++jj) acx[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fr[b][jj][1], acx[jj], 0, 0, 0);
 #pragma unroll
-                for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fr[b][jj][0], acc[jj], 0, 0, 0);
+                    for (int jj = 0; jj < NT; ++jj) acx[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fr[b][jj][0], acx[jj], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fr[b][jj][1], acc[jj], 0, 0, 0);
+#pragma unroll
+                    for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fr[b][jj][0], acc[jj], 0, 0, 0);
+                }
                 if (it + 1 < NI) {
 #pragma unroll
                     for (int q = 0; q < 2 * NT; ++q) {
@@ -240,6 +250,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             nxd = nxd + kSlabB == kRing * kSlabB ? 0u : nxd + kSlabB;
         }
 
+        if (XACC) {
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jj][r] += acx[jj][r];
+        }
         // k-split: the two waves of a pair exchange the halves they do not finish
         if (KS == 2) {
             char* scr = smem + kScrOff + (uint32_t)(ct + CT * ps) * (NT * 4096u);
@@ -429,18 +445,18 @@ float pick_scale(const std::vector<float>& a, const std::vector<float>* b) {
     return std::ldexp(1.0f, 13 - e);        // mx * scale in [4096, 8192): 8x below the fp16 maximum
 }
 
-template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32>
+template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC>
 int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     constexpr int NT = 4 / PS;
     const size_t lds = kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 : 0);
     static bool attr = false;
     if (!attr) {
-        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32>),
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     const int gx = std::max(1, std::min(a.batch, ncu / gy));
-    hipLaunchKernelGGL((af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32>), dim3(gx, gy), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC>), dim3(gx, gy), dim3(256), lds, st, a);
     return 0;
 }
 
@@ -474,6 +490,7 @@ int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::s
         const float s1 = pick_scale(k1, nullptr), s2 = pick_scale(k2, &kr);
         const std::vector<_Float16> p1 = pack_layer(L1, k1.data(), nullptr, s1), p2 = pack_layer(L2, k2.data(), kr.data(), s2);
         rc = dev_upload(n->allocs, &n->w[2 * b], p1.data(), p1.size() * 2);
+
         if (!rc) rc = dev_upload(n->allocs, &n->w[2 * b + 1], p2.data(), p2.size() * 2);
         std::vector<float> bsum(get(s + "_conv2/bias"));
         for (size_t i = 0; i < bsum.size(); ++i) bsum[i] += get(s + "_res/bias")[i];
@@ -515,16 +532,17 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
     a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = n->abl;
     switch (li) {
-        case 0: return launch_cfg<1, 0, 2, 1, 2, false>(st, a, 1, n->ncu);
-        case 1: return launch_cfg<2, 1, 2, 1, 2, false>(st, a, 1, n->ncu);
-        case 2: return launch_cfg<2, 0, 4, 1, 1, false>(st, a, 1, n->ncu);
-        case 3: return launch_cfg<4, 2, 2, 2, 1, false>(st, a, 2, n->ncu);
-        case 4: return launch_cfg<4, 0, 1, 2, 2, false>(st, a, 1, n->ncu);
-        case 5: return launch_cfg<1, 4, 1, 2, 2, true>(st, a, 1, n->ncu);
-        case 6: return launch_cfg<4, 0, 2, 2, 1, false>(st, a, 1, n->ncu);
-        case 7: return launch_cfg<2, 4, 2, 2, 1, false>(st, a, 1, n->ncu);
-        case 8: return launch_cfg<2, 0, 1, 2, 2, false>(st, a, 1, n->ncu);
-        default: return launch_cfg<1, 2, 1, 2, 2, true>(st, a, 1, n->ncu);
+        // <NSM, NSP, CT, KS, PS, OUT32, XACC>: XACC wherever weights + 2 x accumulators + fragments fit 512 registers
+        case 0: return launch_cfg<1, 0, 2, 1, 2, false, true>(st, a, 1, n->ncu);
+        case 1: return launch_cfg<2, 1, 2, 1, 2, false, true>(st, a, 1, n->ncu);
+        case 2: return launch_cfg<2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
+        case 3: return launch_cfg<4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
+        case 4: return launch_cfg<4, 0, 1, 2, 2, false, true>(st, a, 1, n->ncu);
+        case 5: return launch_cfg<1, 4, 1, 2, 2, true, true>(st, a, 1, n->ncu);
+        case 6: return launch_cfg<4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
+        case 7: return launch_cfg<2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
+        case 8: return launch_cfg<2, 0, 1, 2, 2, false, true>(st, a, 1, n->ncu);
+        default: return launch_cfg<1, 2, 1, 2, 2, true, true>(st, a, 1, n->ncu);
     }
 }
 

@@ -783,6 +783,104 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
 }
 
 // ----------------------------------------------------------------------------------------------
+// finished-episode hand-off (main.py:94 q.put): two small kernels compact every finished, not yet popped
+// episode into ONE int32 buffer (include/af_engine.h: af_engine_pack_episodes), in (game, sequence) order
+// ----------------------------------------------------------------------------------------------
+// One 1024-thread workgroup walks the games in chunks of 1024 with an inclusive scan of (episodes, plies); an
+// episode is taken iff every earlier one was taken and it still fits max_eps / max_plies (the taken set is a prefix
+// of the (game, sequence) order).  Writes the header, meta[], final[] and advances ep_popped.
+__global__ __launch_bounds__(1024) void af_pack_scan(EngineParams P, int max_eps, int max_plies, int32_t* __restrict__ out) {
+    __shared__ int s_e[1024], s_p[1024];
+    __shared__ int s_cut;                                       // first game index that did not fit completely
+    const int t = threadIdx.x;
+    int base_e = 0, base_p = 0;
+    int32_t* meta = out + 4;
+    int32_t* fin = out + 4 + (size_t)max_eps * 4;
+    if (t == 0) s_cut = 0x7fffffff;
+    __syncthreads();
+    for (int g0 = 0; g0 < P.G; g0 += 1024) {
+        const int g = g0 + t;
+        int ne = 0, T0 = 0, T1 = 0;
+        uint32_t pop = 0;
+        if (g < P.G) {
+            pop = P.ep_popped[g];
+            ne = (int)(P.ep_seq[g] - pop);                       // 0, 1 or 2 finished episodes wait
+            if (ne >= 1) T0 = P.ep_len[(size_t)g * 2 + (pop & 1u)];
+            if (ne >= 2) T1 = P.ep_len[(size_t)g * 2 + ((pop + 1u) & 1u)];
+        }
+        s_e[t] = ne; s_p[t] = T0 + T1;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {              // Hillis-Steele inclusive scan
+            const int ve = t >= off ? s_e[t - off] : 0, vp = t >= off ? s_p[t - off] : 0;
+            __syncthreads();
+            s_e[t] += ve; s_p[t] += vp;
+            __syncthreads();
+        }
+        const int e_excl = base_e + s_e[t] - ne, p_excl = base_p + s_p[t] - (T0 + T1);
+        int fit = 0;                                             // episodes of this game that fit the caps
+        if (ne >= 1 && e_excl + 1 <= max_eps && p_excl + T0 <= max_plies) {
+            fit = 1;
+            if (ne >= 2 && e_excl + 2 <= max_eps && p_excl + T0 + T1 <= max_plies) fit = 2;
+        }
+        if (g < P.G && fit < ne) atomicMin(&s_cut, g);
+        __syncthreads();
+        const int cut = s_cut;
+        if (g < P.G && g <= cut && fit > 0) {                    // g == cut: its first episode may still fit
+            for (int k = 0; k < fit; ++k) {
+                const uint32_t seq = pop + (uint32_t)k;
+                const int idx = e_excl + k;
+                meta[idx * 4 + 0] = g; meta[idx * 4 + 1] = (int32_t)seq;
+                meta[idx * 4 + 2] = k == 0 ? T0 : T1; meta[idx * 4 + 3] = p_excl + (k == 0 ? 0 : T0);
+                fin[idx] = __float_as_int(P.ep_final[(size_t)g * 2 + (seq & 1u)]);
+            }
+            P.ep_popped[g] = pop + (uint32_t)fit;
+        }
+        __syncthreads();
+        if (cut != 0x7fffffff) {
+            // totals = everything before the cut game + what the cut game itself contributed
+            if (g == cut) {
+                out[0] = e_excl + fit;
+                out[1] = p_excl + (fit >= 1 ? T0 : 0) + (fit >= 2 ? T1 : 0);
+            }
+            break;
+        }
+        base_e += s_e[1023]; base_p += s_p[1023];
+        __syncthreads();
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (s_cut == 0x7fffffff) { out[0] = base_e; out[1] = base_p; }
+        out[2] = 2 * (P.C <= 128 ? 2 : 4); out[3] = P.C;
+    }
+}
+
+// One workgroup per packed episode: copies its T ply records (contiguous in the game's record buffer) into the
+// ply region.  Record r = [key 2*KW2 ints | policy C | visits C | last | action].
+__global__ __launch_bounds__(256) void af_pack_copy(EngineParams P, int max_eps, int32_t* __restrict__ out) {
+    const int idx = blockIdx.x;
+    if (idx >= out[0]) return;
+    const int32_t* meta = out + 4 + (size_t)idx * 4;
+    const int g = meta[0], T = meta[2], poff = meta[3];
+    const uint32_t seq = (uint32_t)meta[1];
+    const int C = P.C, KW2 = 2 * (C <= 128 ? 2 : 4), R = 2 * KW2 + 2 * C + 2;
+    const size_t r0 = ((size_t)g * 2 + (seq & 1u)) * P.max_ply;
+    int32_t* dst = out + 4 + (size_t)max_eps * 5 + (size_t)poff * R;
+    const int32_t* keys = reinterpret_cast<const int32_t*>(P.rec_key + r0 * KW2);
+    const int32_t* pol = reinterpret_cast<const int32_t*>(P.rec_policy + r0 * C);
+    const int32_t* vis = P.rec_visits + r0 * C;
+    for (int i = threadIdx.x; i < T * R; i += blockDim.x) {
+        const int ply = i / R, f = i - ply * R;
+        int32_t v;
+        if (f < 2 * KW2) v = keys[(size_t)ply * 2 * KW2 + f];
+        else if (f < 2 * KW2 + C) v = pol[(size_t)ply * C + (f - 2 * KW2)];
+        else if (f < 2 * KW2 + 2 * C) v = vis[(size_t)ply * C + (f - 2 * KW2 - C)];
+        else if (f == 2 * KW2 + 2 * C) v = P.rec_last[r0 + ply];
+        else v = P.rec_action[r0 + ply];
+        dst[i] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
 struct af_engine {
@@ -791,7 +889,9 @@ struct af_engine {
     int KW;
     std::vector<void*> allocs;
     std::vector<int32_t> h_i32, h_i32b;
-    std::vector<uint32_t> h_seq, h_popped;
+    int32_t* pack_dev = nullptr;      // staging buffer of af_engine_pop_episodes
+    int64_t pack_cap = 0;
+    std::vector<int32_t> pack_host;
     std::vector<u64> h_ct;
 };
 
@@ -830,6 +930,9 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     const int S = cfg->board_size, C = S * S;
     if (S < 2 || C > 256 || cfg->goal < 2 || cfg->goal > S || cfg->simulation_per_step < 1) return AF_ERR_ARG;
     if (mode != AF_MODE_SELFPLAY && mode != AF_MODE_EXTERNAL) return AF_ERR_ARG;
+    // the noise sampler is numpy's legacy gamma for shape < 1 only (include/af_noise.h); the reference uses 0.3
+    if (!(cfg->dirichlet_alpha > 0.0 && cfg->dirichlet_alpha < 1.0)) return AF_ERR_ARG;
+    if (cfg->upper_simulation_per_step < 1 || !(cfg->c_puct >= 0.0)) return AF_ERR_ARG;
     HIP_OK(hipSetDevice(device));
     af_engine* e = new af_engine();
     e->device = device;
@@ -878,7 +981,7 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     HIP_OK(hipMemcpy(P.phase, ph.data(), G * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(P.root_last, rl.data(), G * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(P.tau, tau.data(), G * 8, hipMemcpyHostToDevice));
-    e->h_i32.resize(G); e->h_i32b.resize(G); e->h_seq.resize(G); e->h_popped.assign(G, 0); e->h_ct.resize(G * CT_N);
+    e->h_i32.resize(G); e->h_i32b.resize(G); e->h_ct.resize(G * CT_N);
     *out = e;
     return AF_OK;
 }
@@ -887,6 +990,7 @@ void af_engine_destroy(af_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (void* p : e->allocs) (void)hipFree(p);
+    if (e->pack_dev) (void)hipFree(e->pack_dev);
     delete e;
 }
 
@@ -924,6 +1028,11 @@ int af_engine_set_root(af_engine* e, int32_t game, const uint64_t* key, int32_t 
     if (!e || !key || game < 0 || game >= e->P.G || e->P.mode != AF_MODE_EXTERNAL) return AF_ERR_ARG;
     EngineParams& P = e->P;
     const int KW = e->KW;
+    for (int k = 0; k < KW; ++k) {                 // a position: stones on the board only, no cell owned by both colours
+        if ((key[k] | key[KW + k]) & ~P.boardmask[k]) return AF_ERR_ARG;
+        if (key[k] & key[KW + k]) return AF_ERR_ARG;
+    }
+    if (last_cell < -1 || last_cell >= P.C) return AF_ERR_ARG;
     HIP_OK(hipDeviceSynchronize());
     if (reset_tree) {   // Player.reset(): player.py:48-51
         const size_t hcap = (size_t)P.hash_mask + 1;
@@ -972,36 +1081,64 @@ int af_engine_move_result(af_engine* e, int32_t game, int32_t* action_cell, int3
     return AF_OK;
 }
 
+int64_t af_engine_pack_ints(const af_engine* e, int32_t max_episodes, int32_t max_plies) {
+    if (!e || max_episodes < 0 || max_plies < 0) return AF_ERR_ARG;
+    const int64_t R = 4 * e->KW + 2 * e->P.C + 2;
+    return 4 + (int64_t)max_episodes * 5 + (int64_t)max_plies * R;
+}
+
+int af_engine_pack_episodes(af_engine* e, void* stream, int32_t max_episodes, int32_t max_plies, int32_t* out_dev) {
+    if (!e || e->P.mode != AF_MODE_SELFPLAY || max_episodes < 1 || max_plies < 1 || !out_dev) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(af_pack_scan, dim3(1), dim3(1024), 0, st, e->P, max_episodes, max_plies, out_dev);
+    hipLaunchKernelGGL(af_pack_copy, dim3(max_episodes), dim3(256), 0, st, e->P, max_episodes, out_dev);
+    HIP_OK(hipGetLastError());
+    return AF_OK;
+}
+
+// Host-array form of the hand-off (kept for callers that want padded arrays): one pack on the device, ONE copy of
+// the used prefix to the host, then a scatter on the host.
 int af_engine_pop_episodes(af_engine* e, void* stream, int32_t cap, int32_t* meta, float* final_value,
                            uint64_t* keys, float* policies, int32_t* visits, int32_t* lasts, int32_t* actions) {
     if (!e || e->P.mode != AF_MODE_SELFPLAY || cap < 0) return AF_ERR_ARG;
+    if (cap == 0) return 0;
     EngineParams& P = e->P;
     hipStream_t st = (hipStream_t)stream;
-    const int G = P.G, C = P.C, KW2 = 2 * e->KW, MP = P.max_ply;
-    HIP_OK(hipMemcpyAsync(e->h_seq.data(), P.ep_seq, (size_t)G * 4, hipMemcpyDeviceToHost, st));
+    const int C = P.C, KW2 = 2 * e->KW, MP = P.max_ply, R = 2 * KW2 + 2 * C + 2;
+    const int max_plies = cap * MP > (1 << 18) ? (1 << 18) : cap * MP;           // bounds the staging buffer (<= 264 MB at 11x11)
+    const int64_t ints = af_engine_pack_ints(e, cap, max_plies);
+    if (e->pack_cap < ints) {
+        if (e->pack_dev) (void)hipFree(e->pack_dev);
+        e->pack_dev = nullptr; e->pack_cap = 0;
+        HIP_OK(hipMalloc((void**)&e->pack_dev, (size_t)ints * 4));
+        e->pack_cap = ints;
+    }
+    int rc = af_engine_pack_episodes(e, stream, cap, max_plies, e->pack_dev);
+    if (rc) return rc;
+    const size_t head = 4 + (size_t)cap * 5;
+    e->pack_host.resize(head);
+    HIP_OK(hipMemcpyAsync(e->pack_host.data(), e->pack_dev, head * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    int n = 0;
-    bool changed = false;
-    for (int g = 0; g < G && n < cap; ++g) {
-        while (e->h_popped[g] != e->h_seq[g] && n < cap) {
-            const uint32_t seq = e->h_popped[g];
-            const size_t b = (size_t)g * 2 + (seq & 1u);
-            int32_t T;
-            HIP_OK(hipMemcpy(&T, P.ep_len + b, 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(final_value + n, P.ep_final + b, 4, hipMemcpyDeviceToHost));
-            meta[4 * n] = g; meta[4 * n + 1] = (int32_t)seq; meta[4 * n + 2] = T; meta[4 * n + 3] = 0;
-            const size_t r = b * MP;
-            HIP_OK(hipMemcpy(keys + (size_t)n * MP * KW2, P.rec_key + r * KW2, (size_t)T * KW2 * 8, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(policies + (size_t)n * MP * C, P.rec_policy + r * C, (size_t)T * C * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(visits + (size_t)n * MP * C, P.rec_visits + r * C, (size_t)T * C * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(lasts + (size_t)n * MP, P.rec_last + r, (size_t)T * 4, hipMemcpyDeviceToHost));
-            HIP_OK(hipMemcpy(actions + (size_t)n * MP, P.rec_action + r, (size_t)T * 4, hipMemcpyDeviceToHost));
-            e->h_popped[g] = seq + 1;
-            changed = true;
-            ++n;
+    const int n = e->pack_host[0], np = e->pack_host[1];
+    if (n <= 0) return 0;
+    e->pack_host.resize(head + (size_t)np * R);
+    HIP_OK(hipMemcpyAsync(e->pack_host.data() + head, e->pack_dev + head, (size_t)np * R * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    const int32_t* H = e->pack_host.data();
+    for (int i = 0; i < n; ++i) {
+        const int32_t* m = H + 4 + (size_t)i * 4;
+        const int T = m[2], poff = m[3];
+        meta[4 * i] = m[0]; meta[4 * i + 1] = m[1]; meta[4 * i + 2] = T; meta[4 * i + 3] = 0;
+        memcpy(final_value + i, H + 4 + (size_t)cap * 4 + i, 4);
+        for (int t = 0; t < T; ++t) {
+            const int32_t* r = H + head + (size_t)(poff + t) * R;
+            memcpy(keys + ((size_t)i * MP + t) * KW2, r, (size_t)KW2 * 8);
+            memcpy(policies + ((size_t)i * MP + t) * C, r + 2 * KW2, (size_t)C * 4);
+            memcpy(visits + ((size_t)i * MP + t) * C, r + 2 * KW2 + C, (size_t)C * 4);
+            lasts[(size_t)i * MP + t] = r[2 * KW2 + 2 * C];
+            actions[(size_t)i * MP + t] = r[2 * KW2 + 2 * C + 1];
         }
     }
-    if (changed) HIP_OK(hipMemcpy(P.ep_popped, e->h_popped.data(), (size_t)G * 4, hipMemcpyHostToDevice));
     return n;
 }
 

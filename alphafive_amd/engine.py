@@ -67,6 +67,9 @@ def lib():
         L.af_engine_move_result.argtypes = [vp, C.c_int32, i32p, i32p, f32p, i32p, C.POINTER(C.c_double)]
         L.af_engine_set_training.argtypes = [vp, C.c_int32]
         L.af_engine_pop_episodes.argtypes = [vp, vp, C.c_int32, i32p, f32p, u64p, f32p, i32p, i32p, i32p]
+        L.af_engine_pack_ints.argtypes = [vp, C.c_int32, C.c_int32]
+        L.af_engine_pack_ints.restype = C.c_int64
+        L.af_engine_pack_episodes.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
         L.af_engine_counters.argtypes = [vp, vp, u64p]
         L.af_engine_progress.argtypes = [vp, vp, u64p]
         L.af_engine_tick_histogram.argtypes = [vp, vp, u64p, C.c_int32]
@@ -195,25 +198,37 @@ class Engine:
                    "tree_dump")
         return dict(keys=keys, sum_n=sum_n, n=n, w=w, p=p, f32=f)
 
-    def pop_episodes_raw(self, cap=256, stream=None):
-        MP, Cc, K = self.max_plies, self.C, self.KW2
-        meta = np.zeros((cap, 4), np.int32)
-        fv = np.zeros(cap, np.float32)
-        keys = np.zeros((cap, MP, K), np.uint64)
-        pol = np.zeros((cap, MP, Cc), np.float32)
-        vis = np.zeros((cap, MP, Cc), np.int32)
-        last = np.zeros((cap, MP), np.int32)
-        act = np.zeros((cap, MP), np.int32)
-        n = _check(lib().af_engine_pop_episodes(self._h, stream, cap, _p(meta, C.c_int32), _p(fv, C.c_float),
-                                                _p(keys, C.c_uint64), _p(pol, C.c_float), _p(vis, C.c_int32),
-                                                _p(last, C.c_int32), _p(act, C.c_int32)), "af_engine_pop_episodes")
-        out = []
-        for i in range(n):
-            T = int(meta[i, 2])
-            out.append(dict(game=int(meta[i, 0]), seq=int(meta[i, 1]), T=T, final_value=float(fv[i]),
-                            keys=keys[i, :T].copy(), policies=pol[i, :T].copy(), visits=vis[i, :T].copy(),
-                            lasts=last[i, :T].copy(), actions=act[i, :T].copy()))
-        return out
+    def pack_ints(self, max_eps, max_plies):
+        return int(_check(lib().af_engine_pack_ints(self._h, max_eps, max_plies), "af_engine_pack_ints"))
+
+    def pack_episodes(self, out_ptr, max_eps, max_plies, stream=None):
+        """Device-side hand-off (include/af_engine.h af_engine_pack_episodes): compacts the finished episodes into the
+        int32 buffer at out_ptr (device memory or device-writable pinned host memory) on `stream`.  No sync, no copy."""
+        _check(lib().af_engine_pack_episodes(self._h, stream, max_eps, max_plies, out_ptr), "af_engine_pack_episodes")
+
+
+def unpack_episodes(buf, max_eps):
+    """Packed hand-off buffer (int32 numpy, layout of af_engine_pack_episodes) -> list of raw episode dicts."""
+    buf = np.ascontiguousarray(buf, np.int32)
+    n, _, K, Cc = (int(x) for x in buf[:4])
+    R = 2 * K + 2 * Cc + 2
+    head = 4 + 5 * max_eps
+    out = []
+    for i in range(n):
+        g, seq, T, p0 = (int(x) for x in buf[4 + 4 * i:8 + 4 * i])
+        rec = buf[head + p0 * R:head + (p0 + T) * R].reshape(T, R)
+        out.append(dict(game=g, seq=seq, T=T, final_value=float(buf[4 + 4 * max_eps + i:5 + 4 * max_eps + i].view(np.float32)[0]),
+                        keys=np.ascontiguousarray(rec[:, :2 * K]).view(np.uint64).reshape(T, K).copy(),
+                        policies=np.ascontiguousarray(rec[:, 2 * K:2 * K + Cc]).view(np.float32).copy(),
+                        visits=rec[:, 2 * K + Cc:2 * K + 2 * Cc].copy(),
+                        lasts=rec[:, 2 * K + 2 * Cc].copy(), actions=rec[:, 2 * K + 2 * Cc + 1].copy()))
+    return out
+
+
+def packed_used_ints(hdr, max_eps):
+    """ints of a packed buffer that carry data, from its 4-int header."""
+    n_plies, K, Cc = int(hdr[1]), int(hdr[2]), int(hdr[3])
+    return 4 + 5 * max_eps + n_plies * (2 * K + 2 * Cc + 2)
 
 
 def assemble_episode(raw, S, gamma):
@@ -267,6 +282,7 @@ class SelfPlayEngine:
         if hasattr(pv_device, "bind_outputs"):       # the HIP net writes into our tensors: no copy per tick
             pv_device.bind_outputs(self.policy, self.value)
         self.ticks = 0
+        self._boxes = {}
 
     def tick(self):
         """One simulation step for every game: tree kernel -> leaf batch -> net."""
@@ -296,8 +312,53 @@ class SelfPlayEngine:
     def progress(self):
         return self.engine.progress(self.torch.cuda.current_stream(self.dev).cuda_stream)
 
+    # ---- finished-episode hand-off: pack on the device, written straight into pinned host memory ----
+    def _outbox(self, cap):
+        box = self._boxes.get(cap)
+        if box is None:
+            torch = self.torch
+            max_plies = cap * 40                                   # episodes are ~26 plies; what does not fit waits for the next post
+            ints = self.engine.pack_ints(cap, max_plies)
+            box = dict(cap=cap, max_plies=max_plies, buf=torch.zeros(ints, dtype=torch.int32, pin_memory=True),
+                       event=torch.cuda.Event(), posted=False)
+            self._boxes[cap] = box
+        return box
+
+    def post_episodes(self, cap=256):
+        """Asynchronous half of the hand-off: two small kernels on the tick stream compact the finished episodes into a
+        pinned host buffer (the device writes it directly: no copy, no synchronisation).  collect_episodes() reads it."""
+        box = self._outbox(cap)
+        if box["posted"]:
+            raise EngineError("post_episodes: the previous post has not been collected")
+        stream = self.torch.cuda.current_stream(self.dev)
+        self.engine.pack_episodes(box["buf"].data_ptr(), cap, box["max_plies"], stream.cuda_stream)
+        box["event"].record(stream)
+        box["posted"] = True
+        return box
+
+    def collect_episodes(self, cap=256):
+        """-> raw episode dicts of the last post_episodes(cap) (waits for its event only)."""
+        box = self._outbox(cap)
+        if not box["posted"]:
+            return []
+        box["event"].synchronize()
+        box["posted"] = False
+        return unpack_episodes(box["buf"].numpy(), cap)
+
     def pop_raw(self, cap=256):
-        return self.engine.pop_episodes_raw(cap, self.torch.cuda.current_stream(self.dev).cuda_stream)
+        self.post_episodes(cap)
+        return self.collect_episodes(cap)
+
+    def post_episodes_device(self, cap=256):
+        """Multi-GPU form of post_episodes: the packed buffer stays in device memory (a torch int32 tensor) so that it
+        can be handed to RCCL as it is (alphafive_amd.dist.gather_packed)."""
+        key = ("dev", cap)
+        buf = self._boxes.get(key)
+        if buf is None:
+            buf = self.torch.zeros(self.engine.pack_ints(cap, cap * 40), dtype=self.torch.int32, device=self.dev)
+            self._boxes[key] = buf
+        self.engine.pack_episodes(buf.data_ptr(), cap, cap * 40, self.torch.cuda.current_stream(self.dev).cuda_stream)
+        return buf
 
     def pop_episodes(self, cap=256):
         """-> list of (game_record, result) exactly as main.gen_data puts on its queue (main.py:94)."""

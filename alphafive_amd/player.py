@@ -18,6 +18,7 @@ Noise comes from the engine's counter-based generator (include/af_noise.h), not 
 np.random — seed it with the `seed` keyword.
 """
 import gc
+import os
 from collections.abc import Mapping
 
 import numpy as np
@@ -76,9 +77,20 @@ class TreeView(Mapping):
 
 
 class Player(object):
-    def __init__(self, cfg=None, training=True, pipe=None, pv_fn=None, device=0, seed=0, game_id=0, node_cap=0):
+    _next_game_id = [0]          # process-wide: every Player built without an explicit game_id gets its own noise stream
+
+    def __init__(self, cfg=None, training=True, pipe=None, pv_fn=None, device=0, seed=None, game_id=None, node_cap=0):
         assert pipe is not None or pv_fn is not None
         import torch
+        # The reference's workers draw from process-global MT19937 streams seeded from OS entropy (main.py:82: N workers each
+        # `Player(config, training=True, pipe=pipe)`), so they never repeat each other.  Same here by default: the 64-bit
+        # seed comes from os.urandom and game_id from a process-wide counter; pass both for reproducible runs.
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+        if game_id is None:
+            game_id = Player._next_game_id[0]
+            Player._next_game_id[0] += 1
+        self.seed, self.game_id = seed, game_id
         self.config = cfg
         self.training = training
         self.root_state = None

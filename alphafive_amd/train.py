@@ -103,8 +103,8 @@ def train_loop(config, engine, net, stack, trainer, steps, log=print):
         engine.run_ticks(256)
         engine.check()
         for data_record, result in engine.pop_episodes():
-            r = stack.push(data_record, result)
-            if r and stack.is_full():
+            r = stack.push(data_record, result)         # every popped episode reaches the buffer, also after the last step
+            if r and stack.is_full() and step < steps:
                 for _ in range(4):
                     boards, weights, values, policies = stack.get_data(batch_size=config.batch_size)
                     metrics = trainer.step(boards, weights, values, policies, config.get_lr(step))
@@ -114,6 +114,4 @@ def train_loop(config, engine, net, stack, trainer, steps, log=print):
                     (step, metrics["cross_entropy"], metrics["value_loss"], metrics["entropy"]))
                 if step % 60 == 0:
                     trainer.save(config.ckpt_path, step)
-                if step >= steps:
-                    break
     return step

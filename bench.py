@@ -244,11 +244,30 @@ def main():
             if plies >= target:
                 break
         sp.check()
-        # finished episodes -> rank 0 (RCCL gather over xGMI when world > 1)
-        eps = afdist.gather_episodes(sp.pop_raw(cap=1024), world, rank, comm_dev, game_offset=rank * G)
+        hand_off()
+
+    EP_CAP = 512                                      # episodes per hand-off (~G/26 finish per step; the rest waits)
+    posted = {"buf": None}
+
+    def collect():
+        # finished episodes -> rank 0.  N = 1: the pack kernels wrote them into pinned host memory; N > 1: the packed
+        # device buffer goes through one RCCL all-gather over xGMI (alphafive_amd.dist.gather_packed).
+        if posted["buf"] is None:
+            return
+        if world == 1:
+            eps = sp.collect_episodes(EP_CAP)
+        else:
+            eps = afdist.gather_packed(posted["buf"], EP_CAP, world, rank, comm_dev, games_per_rank=G)
+        posted["buf"] = None
         if rank == 0:
             gathered["episodes"] += len(eps)
             gathered["plies"] += sum(e["T"] for e in eps)
+
+    def hand_off():
+        # collect what was posted one step ago (its kernels retired long ago: nothing waits), then post this step's
+        # episodes behind the ticks already queued — the hand-off never sits on the tick path
+        collect()
+        posted["buf"] = sp.post_episodes(EP_CAP) if world == 1 else sp.post_episodes_device(EP_CAP)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -269,6 +288,7 @@ def main():
     for _ in range(args.steps):
         target += G
         run_step(target)
+    collect()                                         # the last step's episodes
     barrier()
     elapsed = time.perf_counter() - t0
     timing["on"] = False

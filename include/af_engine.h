@@ -109,7 +109,21 @@ int af_engine_move_result(af_engine* e, int32_t game, int32_t* action_cell, int3
                           int32_t* visits, double* tau);
 int af_engine_set_training(af_engine* e, int32_t training);
 
-/* SELFPLAY mode: pop finished episodes (Player.run's return value before value/weight
+/* SELFPLAY mode, device-resident hand-off of finished episodes (main.py:94 `q.put`): two small kernels on `stream`
+ * compact every finished, not yet popped episode — in (game, sequence) order, at most max_episodes episodes and
+ * max_plies plies; the rest waits for the next call — into ONE int32 buffer and mark them popped.  No host
+ * synchronisation, no copy: `out` is device memory (hand it to RCCL) or pinned host memory the device can write
+ * (read it after an event).  Layout, R = 2*KW2 + 2*C + 2 ints per ply:
+ *   out[0] = episodes n, out[1] = plies, out[2] = KW2 (key words), out[3] = C
+ *   out[4 + 4*i ..]                      meta of episode i: game, episode_seq, T, first ply index
+ *   out[4 + 4*max_episodes + i]          final value (float bits): is_game_over value of the last position
+ *   out[4 + 5*max_episodes + R*p ..]     ply p: key (KW2 uint64) | policy float[C] | visits int[C] | last cell | action cell
+ * af_engine_pack_ints = the buffer size in ints for the given caps. */
+int64_t af_engine_pack_ints(const af_engine* e, int32_t max_episodes, int32_t max_plies);
+int af_engine_pack_episodes(af_engine* e, void* stream, int32_t max_episodes, int32_t max_plies, int32_t* out);
+
+/* The same hand-off into caller-allocated padded host arrays (one pack, one copy of the used prefix, synchronous):
+ * pop finished episodes (Player.run's return value before value/weight
  * assembly, which is host-side arithmetic on T and final_value).
  * meta[i] = {game, episode_seq, T, 0}; final_value[i] = is_game_over value of the last
  * position; per ply: keys [cap][max_plies][2KW], policies/visits [cap][max_plies][C],

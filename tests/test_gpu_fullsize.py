@@ -1,7 +1,8 @@
-"""BASELINE.json full size (configs[1]: 4096 concurrent 11x11 games, 500 sims/move) through the C ABI:
-bit-exact visit-count vectors vs the oracle on a sample of games, size-independent invariants on all of
-them, run-to-run determinism, and shard invariance (games g..g+n of a big engine == the same games run in
-their own engine with first_game_id = g — the single-GPU form of the 8-GPU sharding check)."""
+"""BASELINE.json full sizes through the C ABI, in the steady state the metric is defined on: configs[1]
+(4096 concurrent 11x11 games, 500 sims/move) and configs[3] (15x15, 800 sims/move) are run until every game has
+finished at least one episode; complete episodes of sampled games bit-exact vs the oracle, size-independent
+invariants on all games, and shard invariance (games g..g+n of a big engine == the same games run in their own
+engine with first_game_id = g — the single-GPU form of the 8-GPU sharding check)."""
 import numpy as np
 import pytest
 
@@ -13,73 +14,92 @@ pytestmark = pytest.mark.gpu
 SALT, PEAK, SEED = 777, 8192, 42
 
 
-def test_config2_full_size_parity_invariants_and_sharding():
-    import torch
+def _play_until_every_game_finished(sp, G, max_rounds, ticks_per_round=512, cap=512):
+    """-> {game: [raw episodes in order]} once every game has finished at least one episode."""
+    got = {}
+    for _ in range(max_rounds):
+        sp.run_ticks(ticks_per_round)
+        sp.check()
+        while True:
+            raws = sp.pop_raw(cap=cap)
+            for raw in raws:
+                got.setdefault(raw["game"], []).append(raw)
+            if len(raws) < cap // 2:
+                break
+        if len(got) == G:
+            break
+    return got
+
+
+def _assert_episode_equals_oracle(raw, orc, S, gamma):
+    from alphafive_amd.engine import assemble_episode
+    orec, extra = orc.run()
+    assert raw["T"] == len(orec), f"game {raw['game']} seq {raw['seq']}: length"
+    assert (raw["actions"] == extra["actions"]).all() and (raw["visits"] == extra["visits"]).all()
+    assert raw["final_value"] == extra["final_value"]
+    rec, _ = assemble_episode(raw, S, gamma)
+    for (s, p, la, v, w), (os_, op, ola, ov, ow) in zip(rec, orec):
+        assert s == os_ and la == ola and v == ov and w == ow
+        assert (p.view(np.uint32) == op.view(np.uint32)).all()
+
+
+def test_config2_full_size_steady_state_parity_invariants_and_sharding():
+    """BASELINE configs[1] at full size and in the steady state SURVEY §8d defines: 4096 games, 11x11, 500 sims/move
+    (cap 642), run until EVERY game has finished at least one episode — terminal simulations, store collection,
+    episode ends, restarts and the device hand-off all happen at scale (reference: player.py:53-82 run, :73 tree reset).
+    Sampled games' complete episodes are compared with the oracle bit for bit; shard invariance: the last 256 games
+    in their own engine (first_game_id = 3840) reproduce exactly the episodes they produce inside the big engine."""
     from alphafive_amd.engine import SelfPlayEngine
     cfg = make_cfg(simulation_per_step=500, upper_simulation_per_step=642)
     G = 4096
-
-    def run(G_, first, ticks=1030):
-        sp = SelfPlayEngine(cfg, G_, lambda x: pseudonet.pseudonet_torch(x, SALT, PEAK), device=0, seed=SEED,
-                            first_game_id=first)
-        sp.run_ticks(ticks)
-        sp.check()
-        ct = sp.counters()
-        dumps = {g: sp.engine.tree_dump(g) for g in (0, G_ - 1)}
-        sp.close()
-        return ct, dumps, None
-
-    ct, dumps, _ = run(G, 0)
-    # size-independent invariants (SURVEY §8a rule 5 and the counters' bookkeeping)
-    assert ct["plies"] == 2 * G                       # 1030 ticks: every game committed exactly two moves
-    assert ct["sims"] == ct["expands"] + ct["terminals"]
-    assert ct["selects"] >= ct["sims"] and ct["episodes"] == 0
-    for d in dumps.values():
-        # rule 5: sum_n == sum of edge visits, except along the ONE simulation parked at its leaf (select has
-        # counted the node, the backup has not happened yet): those nodes are ahead by exactly 1
-        ahead = d["sum_n"] - d["n"].sum(1)
-        assert ((ahead == 0) | (ahead == 1)).all() and ahead.sum() <= 8
-        assert (d["p"] >= 0).all() and np.isfinite(d["w"]).all()
-        legal_p = d["p"].sum(1)
-        assert np.abs(legal_p - 1.0).max() < 1e-4     # priors renormalised over legal moves
-    # bit-exact trees vs the oracle for the sampled games (same seed, game id, pseudo-net)
-    for g, d in dumps.items():
+    sp = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, SALT, PEAK), device=0, seed=SEED)
+    got = _play_until_every_game_finished(sp, G, max_rounds=200)
+    ct = sp.counters()
+    hist = sp.engine.tick_histogram()
+    sp.close()
+    assert len(got) == G, "some games never finished an episode"
+    # bookkeeping invariants at scale
+    assert ct["sims"] == ct["expands"] + ct["terminals"] and ct["selects"] >= ct["sims"]
+    assert ct["terminals"] > 0 and ct["collector_runs"] > G      # every game collected its store several times
+    assert ct["stalls"] == 0                                     # the hand-off kept up
+    n_eps = sum(len(v) for v in got.values())
+    assert ct["episodes"] >= n_eps >= G
+    lens = np.array([v[0]["T"] for v in got.values()])
+    assert lens.min() >= 9 and lens.max() <= 121
+    for g, eps in got.items():                                   # per game: sequence numbers 0,1,2,... in order
+        assert [e["seq"] for e in eps] == list(range(len(eps)))
+    assert hist["selects"][9:].sum() > 0                         # deep simulations happened; the per-launch budget bounds terminal chains
+    # bit-exact complete episodes vs the oracle: 8 sampled games, every episode each of them finished
+    for g in (0, 1, 777, 1234, 2048, 3000, 4000, G - 1):
         orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
                                   pseudo_salt=SALT, pseudo_peak=PEAK)
-        board = np.zeros((11, 11), np.int8)
-        state, last = oracle.board_to_state(board), None
-        for _ in range(2):                            # the two committed moves
-            _, act, _ = orc.get_action(state, last)
-            board = oracle.step(oracle.state_to_board(state, 11), act)
-            state, last = oracle.board_to_state(board), act
-        # continue the third move's simulations the engine has already done: 1030 ticks = 2 moves + the rest
-        od = orc.tree_dump()
-        omap = {od["keys"][i].tobytes(): i for i in range(len(od["sum_n"]))}
-        hits = 0
-        for i in range(len(d["sum_n"])):
-            k = np.zeros(8, np.uint64)
-            k[:2], k[4:6] = d["keys"][i][:2], d["keys"][i][2:]
-            j = omap.get(k.tobytes())
-            if j is None:
-                continue                              # created by the third move's sims the oracle has not run
-            # nodes untouched by the in-flight third move must be identical; visited ones only grow
-            assert (d["p"][i].view(np.uint32) == od["p"][j].view(np.uint32)).all()
-            assert (d["n"][i] >= od["n"][j]).all()
-            hits += 1
-        assert hits > 500
-    # determinism: the same engine configuration reproduces the same counters and trees
-    ct2, dumps2, _ = run(G, 0)
-    assert ct2 == ct
-    for g in dumps:
-        for k in ("keys", "sum_n", "n"):
-            assert (dumps[g][k] == dumps2[g][k]).all()
-        assert (dumps[g]["w"].view(np.uint32) == dumps2[g]["w"].view(np.uint32)).all()
-    # shard invariance: games 2048..4095 in their own engine == the same games inside the 4096-game engine
-    ct_s, dumps_s, _ = run(2048, 2048)
-    big_last, shard_last = dumps[G - 1], dumps_s[2047]
-    for k in ("keys", "sum_n", "n"):
-        assert (big_last[k] == shard_last[k]).all()
-    assert (big_last["w"].view(np.uint32) == shard_last["w"].view(np.uint32)).all()
+        for raw in got[g][:2 if g in (0, G - 1) else 1]:
+            _assert_episode_equals_oracle(raw, orc, 11, cfg.gamma)
+    # shard invariance (the single-GPU form of SURVEY §8e's check: an N-GPU run = N independent shards)
+    sp2 = SelfPlayEngine(cfg, 256, lambda x: pseudonet.pseudonet_torch(x, SALT, PEAK), device=0, seed=SEED, first_game_id=G - 256)
+    got2 = _play_until_every_game_finished(sp2, 256, max_rounds=200)
+    sp2.close()
+    for g2, eps2 in got2.items():
+        a, b = got[G - 256 + g2][0], eps2[0]
+        assert a["T"] == b["T"] and (a["actions"] == b["actions"]).all() and (a["visits"] == b["visits"]).all()
+        assert (a["policies"].view(np.uint32) == b["policies"].view(np.uint32)).all() and (a["keys"] == b["keys"]).all()
+
+
+def test_config4_15x15_steady_state_episodes_match_oracle():
+    """BASELINE configs[3] search settings (15x15, 800 sims/move, cap 942; 4-word bitboards) on a 256-game engine until
+    every game has finished an episode; sampled games bit-exact against the oracle."""
+    from alphafive_amd.engine import SelfPlayEngine
+    cfg = make_cfg(board_size=15, simulation_per_step=800, upper_simulation_per_step=942)
+    G = 256
+    sp = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, SALT, PEAK), device=0, seed=SEED)
+    got = _play_until_every_game_finished(sp, G, max_rounds=400, cap=256)
+    ct = sp.counters()
+    sp.close()
+    assert len(got) == G and ct["collector_runs"] > 0 and ct["stalls"] == 0
+    for g in (0, 100, G - 1):
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
+                                  pseudo_salt=SALT, pseudo_peak=PEAK)
+        _assert_episode_equals_oracle(got[g][0], orc, 15, cfg.gamma)
 
 
 def test_config4_full_size_15x15_invariants_oracle_and_sharding():

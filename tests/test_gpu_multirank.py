@@ -1,0 +1,82 @@
+"""SURVEY §8e parity check in the only form a 1-GPU box allows: two ranks share GPU 0 (gloo rendezvous), each owns G
+games with game id = rank*G + g and hands its finished episodes to rank 0 through the device pack + all-gather path;
+the multiset rank 0 ends up with must equal what ONE engine of 2G games produces — i.e. an N-rank run is N independent
+shards of the same games.  Also: `bench.py --gpus 2` (the driver's launch line, AF_BENCH_SHARE_GPU=1) prints one
+consistent JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, make_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(args, extra_env=None, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_ranks_produce_the_episodes_of_one_big_engine(tmp_path):
+    import pseudonet
+    import zlib
+    from alphafive_amd.engine import SelfPlayEngine
+    G, ticks = 128, 6000
+    out = str(tmp_path / "rank0.json")
+    r = _launch([os.path.join(REPO, "tests", "multirank_worker.py"), out, str(G), str(ticks)])
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(out) as f:
+        two = json.load(f)
+    cfg = make_cfg(board_size=7, goal=4, simulation_per_step=40, upper_simulation_per_step=60)
+    sp = SelfPlayEngine(cfg, 2 * G, lambda x: pseudonet.pseudonet_torch(x, 555, 8192), device=0, seed=2025)
+    eps = []
+    for _ in range(ticks // 500):
+        sp.run_ticks(500)
+        sp.check()
+        while True:
+            raws = sp.pop_raw(cap=2 * G)
+            eps += raws
+            if len(raws) < 2 * G:
+                break
+    moves = sp.progress()[0]
+    sp.close()
+
+    def digest(e):
+        h = zlib.crc32(np.ascontiguousarray(e["keys"]).tobytes())
+        h = zlib.crc32(np.ascontiguousarray(e["policies"]).tobytes(), h)
+        h = zlib.crc32(np.ascontiguousarray(e["visits"]).tobytes(), h)
+        h = zlib.crc32(np.ascontiguousarray(e["actions"]).tobytes(), h)
+        return [int(e["game"]), int(e["seq"]), int(e["T"]), float(e["final_value"]), int(h)]
+
+    one = sorted(digest(e) for e in eps)
+    assert len(one) > 2 * G                                  # several episodes per game
+    assert one == two["episodes"]                            # the same multiset of episodes, bit for bit (crc of every record)
+    assert {d[0] for d in two["episodes"]} == set(range(2 * G))      # both shards are there
+    assert two["moves"] == moves                              # the all-reduced move counter
+
+
+def test_bench_two_ranks_prints_one_consistent_line():
+    r = _launch([os.path.join(REPO, "bench.py"), "--gpus", "2", "--games", "96", "--board", "6", "--sims", "30", "--upper", "40",
+                 "--steps", "36", "--warmup", "4", "--no-cpu-baseline"], extra_env={"AF_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 36 and d["warmup"] == 4 and d["scaling"] == "weak"
+    assert d["value"] is not None and d["value"] > 0
+    # whole-job aggregate: both ranks' plies over the max-over-ranks time
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 96) < 0.25 * 2 * 96
+    assert d["config"]["episodes_gathered"] >= 2 * 96 * 0.5  # rank 0 received episodes of both shards

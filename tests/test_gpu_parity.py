@@ -238,3 +238,67 @@ def test_selfplay_edge_cases_match_oracle(kw, G):
     if S == 3:
         assert draws > 0, "the 3x3 case is there to exercise drawn games"
     sp.close()
+
+
+def test_unpopped_episodes_apply_back_pressure_and_small_caps_keep_order():
+    """a game that has two finished, unpopped episodes must not start writing a third into the oldest
+    record buffer.  The engine applies back-pressure instead (the reference's Queue(50), main.py:51,94): the game waits
+    at the start of its next episode until the host pops.  Nothing is popped for a long time here, then the episodes
+    are popped with caps far smaller than what is pending (the rest must wait for the next call, in order), mid-way
+    through the games' resumed play; every episode must still equal the oracle's."""
+    from alphafive_amd.engine import SelfPlayEngine
+    S, G = 6, 24
+    cfg = make_cfg(board_size=S, goal=4, simulation_per_step=20, upper_simulation_per_step=30)
+    salt, peak, seed = 4321, 8192, 99
+    sp = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, salt, peak), device=0, seed=seed)
+    sp.run_ticks(6000)                           # far more than two episodes' worth (an episode is <= 36 plies x 20 sims)
+    sp.check()
+    ct = sp.counters()
+    assert ct["episodes"] == 2 * G and ct["stalls"] > 0, ct       # every game finished exactly two episodes, then waited
+    got = {}
+    first = sp.pop_raw(cap=5)                    # caps smaller than the 48 pending episodes: a prefix in (game, seq) order
+    assert [(r["game"], r["seq"]) for r in first] == [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]
+    for r in first:
+        got.setdefault(r["game"], []).append(r)
+    sp.run_ticks(300)                            # games 0 and 1 resume (mid-episode now), game 2 has one buffer free
+    for rnd in range(40):
+        raws = sp.pop_raw(cap=7 if rnd < 3 else 64)   # (small caps serve low-numbered games first: do not starve the rest)
+        for r in raws:
+            got.setdefault(r["game"], []).append(r)
+        sp.run_ticks(200)
+        sp.check()
+        if all(len(got.get(g, [])) >= 4 for g in range(G)):
+            break
+    assert all(len(got.get(g, [])) >= 4 for g in range(G))
+    for g in range(G):
+        assert [e["seq"] for e in got[g]] == list(range(len(got[g])))
+    for g in range(0, G, 4):
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=seed, game_id=g,
+                                  pseudo_salt=salt, pseudo_peak=peak)
+        for raw in got[g][:4]:
+            orec, extra = orc.run()
+            assert raw["T"] == len(orec) and (raw["actions"] == extra["actions"]).all(), f"game {g} seq {raw['seq']}"
+            assert (raw["visits"] == extra["visits"]).all() and raw["final_value"] == extra["final_value"]
+            assert (raw["lasts"][1:] == raw["actions"][:-1]).all() and raw["lasts"][0] == -1
+    sp.close()
+
+
+def test_engine_rejects_bad_configuration_and_roots():
+    from alphafive_amd import engine as eng
+    with pytest.raises(eng.EngineError):         # numpy's shape >= 1 gamma branch is not implemented: refuse, do not mis-sample
+        eng.Engine(make_cfg(dirichlet_alpha=1.5), 1)
+    with pytest.raises(eng.EngineError):
+        eng.Engine(make_cfg(dirichlet_alpha=0.0), 1)
+    e = eng.Engine(make_cfg(board_size=6, goal=4), 1, mode=eng.MODE_EXTERNAL)
+    key = eng.state_to_key("g/g/g/g/g/g/", 6)
+    bad = key.copy()
+    bad[0] |= np.uint64(1) << np.uint64(40)      # bit 40 >= 36 cells
+    with pytest.raises(eng.EngineError):
+        e.set_root(0, bad)
+    both = key.copy()
+    both[0] |= np.uint64(2)
+    both[2] |= np.uint64(2)                      # a cell owned by both colours
+    with pytest.raises(eng.EngineError):
+        e.set_root(0, both)
+    e.set_root(0, key)
+    e.close()

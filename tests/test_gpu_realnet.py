@@ -202,8 +202,8 @@ def test_player_pipe_mode_through_networkapi_matches_pv_fn_mode():
     net.load_npz(W)
     cfg = make_cfg(simulation_per_step=40, upper_simulation_per_step=60)
     pipe = net.get_pipes(cfg)
-    a = Player(cfg, training=True, pipe=pipe, seed=4)
-    b = Player(cfg, training=True, pv_fn=net.eval, seed=4)
+    a = Player(cfg, training=True, pipe=pipe, seed=4, game_id=0)
+    b = Player(cfg, training=True, pv_fn=net.eval, seed=4, game_id=0)      # same noise stream on purpose
     b._pv_device = None                      # force the host round trip so both go through ResNet.eval
     state, last = a.get_init_state(), None
     for _ in range(3):

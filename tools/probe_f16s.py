@@ -57,16 +57,25 @@ for i, (r, nm) in enumerate(zip(refs, names)):
     err = np.abs(buf - ref)
     print("%-10s C=%3d rc=%d  max|err| %.3e  (max|ref| %.2f)  worst at %s" % (nm, Cc, rc, err.max(), np.abs(ref).max(),
           np.unravel_index(err.argmax(), err.shape)), flush=True)
-p64, v64 = net_fp64.forward(net.variables, x[:96])
-print("final: max|dv| %.3e max|dp| %.3e (bar 1e-5)" % (np.abs(v[:96] - v64).max(), np.abs(p[:96] - p64).max()), flush=True)
+NREF = int(os.environ.get("NREF", 96))
+p64, v64 = net_fp64.forward(net.variables, x[:NREF])
+print("final (%d positions): max|dv| %.3e max|dp| %.3e (bar 1e-5)" % (NREF, np.abs(v[:NREF] - v64).max(), np.abs(p[:NREF] - p64).max()), flush=True)
+for mode, bits in ((1, 0),):
+    net_hip.tune(0, mode); net_hip.tune(7, bits)
+    pm, vm = hn(xt)
+    pm, vm = pm.cpu().numpy(), vm.cpu().numpy()
+    print("  conv path %d opt %d: max|dv| %.3e max|dp| %.3e" % (mode, bits, np.abs(vm[:NREF] - v64).max(), np.abs(pm[:NREF] - p64).max()), flush=True)
+pt, vt = net.eval_device(xt)
+print("  PyTorch-ROCm fp32 ops: max|dv| %.3e max|dp| %.3e" % (np.abs(vt.cpu().numpy()[:NREF] - v64).max(), np.abs(pt.cpu().numpy()[:NREF] - p64).max()), flush=True)
+net_hip.tune(0, 5); net_hip.tune(7, 0)
 # determinism
 p2, v2 = hn(xt)
 print("deterministic:", bool((p2.cpu().numpy() == p).all() and (v2.cpu().numpy() == v).all()))
 
 # timing
 xb = torch.from_numpy(_positions(11, B, seed=1)).cuda()
-for mode in (1, 5):
-    net_hip.tune(0, mode)
+for mode, br in ((1, 1), (5, 1), (5, 0)):
+    net_hip.tune(0, mode); net_hip.tune(4, br)
     for _ in range(3):
         hn(xb)
     torch.cuda.synchronize()
@@ -76,10 +85,11 @@ for mode in (1, 5):
         hn(xb)
     e1.record()
     torch.cuda.synchronize()
-    print("mode %d: %.3f ms per forward of %d positions" % (mode, e0.elapsed_time(e1) / 20, B), flush=True)
+    print("mode %d (value branch on side stream: %d): %.3f ms per forward of %d positions" % (mode, br, e0.elapsed_time(e1) / 20, B), flush=True)
+net_hip.tune(4, 1)
 if os.environ.get("ABL"):
     net_hip.tune(0, 5)
-    for bits in (1, 2, 3, 4, 6):
+    for bits in (1, 2, 3):
         net_hip.tune(7, bits)
         for _ in range(2):
             hn(xb)
