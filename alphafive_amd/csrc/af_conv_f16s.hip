@@ -53,7 +53,7 @@ constexpr uint32_t kLds0 = 256u;                // slack so that unit -1 of a sl
 #define AF_F16S_DIST 3
 #endif
 constexpr int kDist = AF_F16S_DIST;             // prefetch distance in slabs: slab t multiplies while t+1 .. t+kDist land
-constexpr int kRing = kDist + 1;                // LDS slots
+constexpr int kRing = kDist + 2;                // LDS slots (see the fragment prefetch in the kernel)
 constexpr uint32_t kZoff = kLds0 + kRing * kSlabB; // all-zero region (edge lanes)
 constexpr uint32_t kBiasOff = kZoff + kSlabB;   // 128 floats
 constexpr uint32_t kScrOff = kBiasOff + 512u;   // k-split exchange
@@ -98,11 +98,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     int pos = blockIdx.x;
     if (pos >= A.batch) return;
 
+    // slab j of a position: the NSP slabs of the projection input first, then the NSM slabs of the 3x3 input (the other
+    // order — long slabs first, so that the epilogue's stores have more time before the next wait on vmcnt — measured
+    // 1.58 vs 1.55 ms per forward and moved |dp| from 6.0e-6 to 8.1e-6)
     auto slab_src = [&](int p, int j) -> const char* {
         return j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabB : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabB;
     };
-    // piece wv + 4q of a slab, q = 0..3: every wave issues exactly 4 LDS-DMA instructions per slab, so that
-    // "s_waitcnt vmcnt(4 * (kDist - 1))" means "everything but the kDist - 1 slabs requested last has landed".  A piece
+    // piece wv + 4q of a slab, q = 0..3: every wave issues exactly 4 LDS-DMA instructions per slab, right after that
+    // slab's barrier, so that "s_waitcnt vmcnt(4 * (kDist - 1))" in front of the next barrier means "everything but the
+    // kDist - 1 slabs requested last has landed".  A piece
     // is 64 units of one unit row: units 8..71 or 72..135 (pixels sit at units 11..131; the other units of a slot are
     // zeroed once and never written).
     auto dma_piece = [&](const char* src, uint32_t slot_off, int q) {
@@ -161,9 +165,35 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    // B fragment of an item (k-step c, tap) of a projection / main slab, half p, for the pixel tile whose centre / left /
+    // right read bases are given
+    auto rd = [](const char* sm, bool proj, int it, int p, uint32_t c_, uint32_t l_, uint32_t r_) -> h8 {
+        const int c = proj ? it : it / 9, tap = proj ? 4 : it % 9, ky = tap / 3, kx = tap % 3;
+        const uint32_t base = kx == 0 ? l_ : (kx == 2 ? r_ : c_);
+        const uint32_t imm = (uint32_t)p * kHalfB + (KS == 1 ? 2u * c * kRowB : 0u) + (uint32_t)(ky * kS + kx) * 16u;
+        return *reinterpret_cast<const h8*>(sm + base + imm);
+    };
+
     uint32_t t = 0;
     uint32_t cur = 0u, nxd = (uint32_t)kDist * kSlabB;        // ring slots of slab t and of slab t + kDist
+    // Fragments are double buffered per item and prefetched one item ahead ACROSS slab (and position) boundaries: the
+    // wait + barrier that publishes slab t+1 sits in front of the LAST item of slab t, whose MFMAs then cover the LDS
+    // latency of slab t+1's first fragments.  (Hence kRing = kDist + 2: the slot that LDS-DMA refills during slab t is
+    // the one of slab t-2, which every wave left before the barrier inside slab t-1.)
+    // XPOS: the prefetch also crosses the position boundary (the fragments stay live through the epilogue) — not where
+    // weights + accumulators already fill the register file (4 pixel tiles and >= 288 weight registers)
+    constexpr bool XPOS = !(NT == 4 && NIT >= 36);
+    h8 fr[2][NT][2];
+#define AF_FIRST_ITEM(slot)                                                                                      \
+    _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                          \
+        const uint32_t c_ = lb[jj] + (slot), l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_;         \
+        fr[0][jj][0] = rd(smem, NSP > 0, 0, 0, c_, l_, r_);                                                      \
+        fr[0][jj][1] = rd(smem, NSP > 0, 0, 1, c_, l_, r_);                                                      \
+    }
+    if (XPOS) { AF_FIRST_ITEM(0u) }
     for (; pos < A.batch; pos += gridDim.x) {
+        if (!XPOS) { AF_FIRST_ITEM(cur) }
+#undef AF_FIRST_ITEM
         // XACC: the cross terms (W_hi*X_lo, W_lo*X_hi; 2^-11 of the main term) get their own accumulator, so the main
         // accumulator is rounded once per item instead of three times (the MFMA's fp32 accumulation is where this path
         // loses accuracy); used where the register budget allows it
@@ -175,11 +205,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
 #pragma clang loop unroll(full)
         for (int j = 0; j < SPP; ++j) {
-            const bool proj = j < NSP;
+            const bool proj = j < NSP, nproj = (j + 1) % SPP < NSP;        // this slab / the next slab of the stream
             const int NI = proj ? ITP : ITM;
             const int ibase = proj ? j * ITP : NSP * ITP + (j - NSP) * ITM;
-            const bool more = t + kDist < nslabs && !(A.abl & 1);
-            const char* nsrc = stream_src((A.abl & 4) ? (t % SPP) : (more ? t + kDist : t));   // abl bit 2: re-request the first position's slabs (L2-hot)
+            // slab t + kDist of the stream: j is static (the loop is unrolled), so which position / slab that is costs no division
+            const int npos = pos + ((j + kDist) / SPP) * (int)gridDim.x;
+            const bool more = npos < A.batch && !(A.abl & 1);
+            const char* nsrc = slab_src((A.abl & 4) ? pos0 : (more ? npos : pos), (j + kDist) % SPP);   // abl bit 2: the first position's slabs again (L2-hot)
+            const uint32_t nx1 = cur + kSlabB == kRing * kSlabB ? 0u : cur + kSlabB;     // slot of slab t+1
             uint32_t bC[NT], bL[NT], bR[NT];
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
@@ -187,27 +220,35 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 bL[jj] = edgeL[jj] ? zb[jj] : bC[jj];
                 bR[jj] = edgeR[jj] ? zb[jj] : bC[jj];
             }
-            // B fragment of item `it` (k-step c, tap), half p, for the pixel tile whose centre / left / right bases are given
-            auto rd = [proj](const char* sm, int it, int p, uint32_t c_, uint32_t l_, uint32_t r_) -> h8 {
-                const int c = proj ? it : it / 9, tap = proj ? 4 : it % 9, ky = tap / 3, kx = tap % 3;
-                const uint32_t base = kx == 0 ? l_ : (kx == 2 ? r_ : c_);
-                const uint32_t imm = (uint32_t)p * kHalfB + (KS == 1 ? 2u * c * kRowB : 0u) + (uint32_t)(ky * kS + kx) * 16u;
-                return *reinterpret_cast<const h8*>(sm + base + imm);
-            };
-            h8 fr[2][NT][2];
-#pragma unroll
-            for (int jj = 0; jj < NT; ++jj) {
-                fr[0][jj][0] = rd(smem, 0, 0, bC[jj], bL[jj], bR[jj]);
-                fr[0][jj][1] = rd(smem, 0, 1, bC[jj], bL[jj], bR[jj]);
-            }
 #pragma clang loop unroll(full)
             for (int it = 0; it < NI; ++it) {
-                const int b = it & 1;
+                const int b = (ibase + it) & 1;
                 if (it + 1 < NI) {
 #pragma unroll
                     for (int jj = 0; jj < NT; ++jj) {
-                        fr[b ^ 1][jj][0] = rd(smem, it + 1, 0, bC[jj], bL[jj], bR[jj]);
-                        fr[b ^ 1][jj][1] = rd(smem, it + 1, 1, bC[jj], bL[jj], bR[jj]);
+                        fr[b ^ 1][jj][0] = rd(smem, proj, it + 1, 0, bC[jj], bL[jj], bR[jj]);
+                        fr[b ^ 1][jj][1] = rd(smem, proj, it + 1, 1, bC[jj], bL[jj], bR[jj]);
+                    }
+                } else {
+                    // last item of slab t: slab t+1 must have landed for every wave — only what was requested AFTER its pieces
+                    // may still be in flight: kDist - 2 whole slabs and the pieces of slab t + kDist this slab has issued
+                    // so far (one per earlier item, at most 4) — then fetch slab t+1's first fragments
+                    const int issued = NI - 1 < 4 ? NI - 1 : 4;
+                    if (more) {
+                        if (issued == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 2) + 4) : "memory");
+                        else if (issued == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 2) + 1) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 2)) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    if ((XPOS || j + 1 < SPP) && t + 1 < nslabs) {
+#pragma unroll
+                        for (int jj = 0; jj < NT; ++jj) {
+                            const uint32_t c_ = lb[jj] + nx1, l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_;
+                            fr[b ^ 1][jj][0] = rd(smem, nproj, 0, 0, c_, l_, r_);
+                            fr[b ^ 1][jj][1] = rd(smem, nproj, 0, 1, c_, l_, r_);
+                        }
                     }
                 }
                 const h8 wh = W[2 * (ibase + it)], wl = W[2 * (ibase + it) + 1];
@@ -224,30 +265,29 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                     for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fr[b][jj][0], acc[jj], 0, 0, 0);
                 }
-                if (it + 1 < NI) {
 #pragma unroll
-                    for (int q = 0; q < 2 * NT; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
+                for (int q = 0; q < 2 * NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
                 }
-                if (it < 4 && more) dma_piece(nsrc, nxd, it);              // slab t + kDist: one 1 KB piece per item
-            }
-            if (more) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                // slab t + kDist (its slot was slab t-2's: free since the barrier inside slab t-1): this wave's 4 pieces of 1 KB,
+                // one per item, the rest behind the last item
+                if (more) {
+                    if (it < NI - 1 && it < 4) dma_piece(nsrc, nxd, it);
+                    if (it == NI - 1) {
 #pragma unroll
-                for (int q = NI; q < 4; ++q) dma_piece(nsrc, nxd, q);
-                // slab t+1 has landed: only the pieces of the kDist - 1 slabs requested after it may be in flight
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 1)) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        for (int q = (NI - 1 < 4 ? NI - 1 : 4); q < 4; ++q) dma_piece(nsrc, nxd, q);
+                    }
+                }
             }
-            __builtin_amdgcn_s_barrier();                                    // ... for every wave, and all are done with slab t
             ++t;
-            cur = cur + kSlabB == kRing * kSlabB ? 0u : cur + kSlabB;
+            cur = nx1;
             nxd = nxd + kSlabB == kRing * kSlabB ? 0u : nxd + kSlabB;
+        }
+        if (XPOS && (NIT & 1)) {                                             // keep the fragment parity static per position
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) { fr[0][jj][0] = fr[1][jj][0]; fr[0][jj][1] = fr[1][jj][1]; }
         }
 
         if (XACC) {
