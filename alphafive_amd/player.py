@@ -161,7 +161,16 @@ class Player(object):
         self._engine.set_root(0, key, last_cell, random_a, reset_tree=self._reset_pending)
         self._reset_pending = False
         stream = self._torch.cuda.current_stream(self._dev).cuda_stream
-        while True:
+        # device evaluator (pv_fn is a ResNet.eval bound method): nothing has to cross the host boundary per leaf, so
+        # ticks and evaluations are queued 16 at a time and the status word is read once per batch (a game whose move
+        # is decided ignores further ticks)
+        while self._pv_device is not None:
+            for _ in range(16):
+                self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), stream)
+                self._evaluate_leaf()
+            if int(self._engine.status(stream)[0]) == _eng.STATUS_MOVE_DONE:
+                break
+        while self._pv_device is None:
             self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), stream)
             st = int(self._engine.status(stream)[0])
             if st == _eng.STATUS_NEED_EVAL:

@@ -49,9 +49,11 @@ def tree_bytes(ct, C):
             + (32 + 16 * C + 4) * ct["expands"] + R * ct["sims"])
 
 
-def cpu_baseline(cfg, weights, budget_s=20.0, game_id=0):
-    """The C oracle (oracle/af_oracle.c, "port") + torch-CPU fp32 net on ONE host core: the same
-    config-2 search for one game, first plies until the time budget is spent."""
+def cpu_baseline(cfg, weights, budget_s=15.0, game_id=0, training=True, whole_game=False):
+    """The C oracle (oracle/af_oracle.c, "port") + torch-CPU fp32 net on ONE host core.  training=True: the config-2
+    search for one game (plies until the time budget is spent, or the complete episode with whole_game).
+    training=False: BASELINE config 1 — the eval-mode loop of self_play.py:79-106 (last_action=None at every root, tree
+    kept and shared by both colours) for the whole game."""
     import torch
     import oracle
     from alphafive_amd.network import ResNet
@@ -59,23 +61,47 @@ def cpu_baseline(cfg, weights, budget_s=20.0, game_id=0):
     net = ResNet(cfg.board_size, device="cpu", seed=0)
     if weights:
         net.load_npz(weights)
-    pl = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=0, game_id=game_id, pv_fn=net.eval)
+    pl = oracle.OraclePlayer(cfg, training=training, rng_mode=oracle.RNG_PHILOX, seed=0, game_id=game_id, pv_fn=net.eval)
     board = np.zeros((cfg.board_size, cfg.board_size), np.int8)
-    state, last, plies = oracle.board_to_state(board), None, 0
+    state, last, plies, over = oracle.board_to_state(board), None, 0, False
     t0 = time.time()
-    while time.time() - t0 < budget_s:
-        _, act, _ = pl.get_action(state, last)
+    while whole_game or time.time() - t0 < budget_s:
+        _, act, _ = pl.get_action(state, last if training else None)
         board = oracle.step(oracle.state_to_board(state, cfg.board_size), act)
         state, last, plies = oracle.board_to_state(board), act, plies + 1
         if oracle.is_game_over(board, cfg.goal)[0]:
+            over = True
+            break
+        if whole_game and time.time() - t0 > 4 * budget_s:      # safety net for a pathological game
             break
     dt = time.time() - t0
     st = pl.stats()
     pl.close()
-    return {"value": plies / dt, "unit": "moves/s", "cores": 1, "kind": "port", "plies": plies, "dt": dt,
-            "sample": f"1 game, first {plies} plies of config 2 (11x11, {cfg.simulation_per_step} sims/move, "
-                      f"training mode), C oracle + torch-CPU fp32 net, 1 thread, {dt:.1f} s, "
-                      f"{st['sims']} sims / {st['expands']} net evals"}
+    what = ("complete %d-ply game" % plies) if over else ("first %d plies" % plies)
+    mode = "training mode (config 2 search)" if training else "eval mode (config 1: self_play.py loop)"
+    return {"value": plies / dt, "unit": "moves/s", "cores": 1, "kind": "port", "plies": plies, "dt": dt, "complete": over,
+            "sample": f"1 game, {what}, 11x11, {cfg.simulation_per_step} sims/move, {mode}, C oracle + torch-CPU fp32 net, "
+                      f"1 thread, {dt:.1f} s, {st['sims']} sims / {st['expands']} net evals"}
+
+
+def cpu_tree_only(cfg, budget_s=3.0):
+    """Tree-only search rate of the C oracle with its built-in integer pseudo-net (no network time): sims/s, directly
+    comparable with the 341 sims/s of the reference's Python tree."""
+    import oracle
+    pl = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=0, game_id=0, pseudo_salt=777, pseudo_peak=8192)
+    board = np.zeros((cfg.board_size, cfg.board_size), np.int8)
+    state, last = oracle.board_to_state(board), None
+    t0 = time.time()
+    while time.time() - t0 < budget_s:
+        _, act, _ = pl.get_action(state, last)
+        board = oracle.step(oracle.state_to_board(state, cfg.board_size), act)
+        state, last = oracle.board_to_state(board), act
+        if oracle.is_game_over(board, cfg.goal)[0]:
+            break
+    dt = time.time() - t0
+    sims = pl.stats()["sims"]
+    pl.close()
+    return sims / dt
 
 
 def usable_cores():
@@ -102,9 +128,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline_all_cores(cfg, weights, budget_s=10.0, max_workers=64):
+def cpu_baseline_all_cores(cfg, weights, budget_s=9.0, max_workers=64):
     """one game per host core, every worker the same 1-thread C oracle + torch-CPU net as
-    cpu_baseline(); aggregate moves/s = all plies / the slowest worker's time."""
+    cpu_baseline(), each playing one COMPLETE training-mode episode (cut at 4 x budget_s); aggregate moves/s = all
+    plies / the slowest worker's time."""
     import subprocess
     n = max(1, min(usable_cores(), max_workers))
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", AF_CPU_WORKER="1")
@@ -121,16 +148,17 @@ def cpu_baseline_all_cores(cfg, weights, budget_s=10.0, max_workers=64):
     if not res:
         return None
     plies, dt = sum(r["plies"] for r in res), max(r["dt"] for r in res)
+    done = sum(1 for r in res if r.get("complete"))
     return {"value": plies / dt, "unit": "moves/s", "cores": len(res), "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
-            "sample": f"{len(res)} processes x 1 game x 1 thread, first plies of config 2 for {budget_s:.0f} s each "
-                      f"({plies} plies in {dt:.1f} s)"}
+            "sample": f"{len(res)} processes x 1 game x 1 thread, one complete training-mode episode each ({done} finished, the rest "
+                      f"cut at {4 * budget_s:.0f} s): {plies} plies, slowest worker {dt:.1f} s"}
 
 
 def _cpu_worker(args):
     cfg = make_cfg(args.sims, args.upper, args.board)
     weights = os.path.join(REPO, "tests", "golden", "alphaFive-6960.weights.npz")
-    r = cpu_baseline(cfg, weights if cfg.board_size == 11 else None, budget_s=args.cpu_worker, game_id=args.seed)
-    print(json.dumps({"plies": r["plies"], "dt": r["dt"]}), flush=True)
+    r = cpu_baseline(cfg, weights if cfg.board_size == 11 else None, budget_s=args.cpu_worker, game_id=args.seed, whole_game=True)
+    print(json.dumps({"plies": r["plies"], "dt": r["dt"], "complete": r["complete"]}), flush=True)
 
 
 def copy_bandwidth_gbs(dev, mib=1024, reps=10):
@@ -389,8 +417,18 @@ def main():
                               "(SURVEY 8d); use the defaults (--warmup 8 --steps 20)")
             out["opening_phase_moves_per_s"] = total_plies / t
         if not args.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(cfg, weights if cfg.board_size == 11 else None)
-            out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, weights if cfg.board_size == 11 else None)
+            w11 = weights if cfg.board_size == 11 else None
+            cb = cpu_baseline(cfg, w11)                                            # the bench's own workload, 1 core
+            # (1) config 1 (eval mode, whole game), (2) every usable core on complete episodes, (3) tree only.
+            # Flat keys: the driver's parser keeps scalars.
+            c1 = cpu_baseline(cfg, w11, training=False, whole_game=True)
+            cb.update({"config1_eval_mode_value": c1["value"], "config1_eval_mode_sample": c1["sample"],
+                       "tree_only_sims_per_s": cpu_tree_only(cfg)})
+            ac = cpu_baseline_all_cores(cfg, w11)
+            if ac:
+                cb.update({"all_cores_value": ac["value"], "all_cores_cores": ac["cores"], "all_cores_host_cores": ac["host_cores"],
+                           "all_cores_sample": ac["sample"]})
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     sp.close()
     if world > 1:
