@@ -34,13 +34,13 @@
 
 typedef unsigned long long u64;
 
-enum { PH_IDLE = 0, PH_MOVE_START = 1, PH_SEARCH = 2, PH_MOVE_DONE = 3, PH_ERROR = 4 };
+enum { PH_IDLE = 0, PH_MOVE_START = 1, PH_SEARCH = 2, PH_MOVE_DONE = 3, PH_ERROR = 4, PH_DESCENT = 5 /* yielded inside a simulation */ };
 enum { CT_SIMS = 0, CT_SELECTS, CT_EXPANDS, CT_TERMINALS, CT_PLIES, CT_EPISODES, CT_LSUM, CT_LEXP,
        CT_GC, CT_GC_SCANNED, CT_YIELDS, CT_STALLS, CT_N };
 enum { HIST_WORK = 0, HIST_TIME = 64, HIST_MAXTIME = 96, HIST_N = 97 };   // selects per launch | 8-us wave-time bins | max wave time (10 ns units)
 
 struct EngineParams {
-    int G, S, C, goal, sims, upper, training, mode, node_cap, max_ply, budget;
+    int G, S, C, goal, sims, upper, training, mode, node_cap, max_ply, budget, budget_hard;
     uint32_t hash_mask;
     double init_temp, tau_decay, tau_decay_r, alpha, c_puct;
     float c_puct32;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         // every other wave has long parked; after `budget` selects the game yields at the next simulation
         // boundary instead (its slot of the leaf batch idles for one tick; the order of simulations inside
         // the game, and so every result, is unchanged).
-        if (work >= P.budget) { status = AF_STATUS_YIELD; parked = true; ct[CT_YIELDS]++; break; }
+        if (work >= P.budget && phase != PH_DESCENT) { status = AF_STATUS_YIELD; parked = true; ct[CT_YIELDS]++; break; }
         if (phase == PH_MOVE_START) {
             // SELFPLAY back-pressure (the reference's Queue(50), main.py:51,94): an episode may only start
             // when its record buffer has been popped; until then the game waits here.
@@ -603,9 +603,20 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
 
         // ------------- one simulation: player.py:204-228 MCTS_search -------------
         u64 cm[KW], ctb[KW];
+        int last, depth;
+        if (phase == PH_DESCENT) {       // resume the descent this game yielded in (hard cap below): position, depth and last move
 #pragma unroll
-        for (int k = 0; k < KW; ++k) { cm[k] = root_m[k]; ctb[k] = root_t[k]; }
-        int last = root_last, depth = 0;
+            for (int k = 0; k < KW; ++k) {
+                cm[k] = rfl64(P.leaf[(size_t)g * 2 * KW + k]);
+                ctb[k] = rfl64(P.leaf[(size_t)g * 2 * KW + KW + k]);
+            }
+            last = rfli(P.leaf_last[g]); depth = rfli(P.depth[g]);
+            phase = PH_SEARCH;
+        } else {
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { cm[k] = root_m[k]; ctb[k] = root_t[k]; }
+            last = root_last; depth = 0;
+        }
         for (;;) {
             float tv;
             if (terminal_test<KW>(P, cm, ctb, &tv)) {                       // :213-217
@@ -632,6 +643,14 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 }
                 status = AF_STATUS_NEED_EVAL;
                 parked = true;
+                break;
+            }
+            // hard cap: a single simulation can descend 30 levels late in a game; past `budget_hard` selects in this launch the
+            // game yields in front of its next select and resumes here at the next tick (path and position are in memory)
+            if (work >= P.budget_hard) {
+                if (lane < 2 * KW) P.leaf[(size_t)g * 2 * KW + lane] = key_word<KW>(cm, ctb, lane);
+                if (lane == 0) { P.depth[g] = depth; P.leaf_last[g] = last; }
+                phase = PH_DESCENT; status = AF_STATUS_YIELD; parked = true; ct[CT_YIELDS]++;
                 break;
             }
             // ------------- player.py:230-279 select_action_q_and_u -------------
@@ -662,20 +681,24 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 // all its variates; the rounds of a cell are indexed by the counter, so the values are those
                 // of af_gamma_lt1 cell by cell)
                 {
-                    const double inv_a = 1.0 / P.alpha, one_m_a = 1.0 - P.alpha;
+                    const float a_ = (float)P.alpha, inv_a = 1.0f / a_, one_m_a = 1.0f - a_;
                     uint32_t todo = 0;
 #pragma unroll
                     for (int k = 0; k < KW; ++k) { dd[k] = 0.0; todo |= ((legal[k] >> lane) & 1ull) ? (1u << k) : 0u; }
                     uint32_t it = 0;
+                    af_u32x4 r;
+                    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
                     while (todo) {
                         const int k = __builtin_ctz(todo);
-                        double X;
-                        const int ok = af_gamma_round(P.alpha, inv_a, one_m_a,
-                                                      af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * k), it, k0, k1), &X);
+                        // one Philox block feeds two rounds of a cell (a lane stays on its cell until it accepts)
+                        if ((it & 1u) == 0u) r = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * k), it >> 1, k0, k1);
+                        const uint32_t wu = (it & 1u) ? r.v[2] : r.v[0], wv = (it & 1u) ? r.v[3] : r.v[1];
+                        float X;
+                        const int ok = af_gamma_round(a_, inv_a, one_m_a, wu, wv, &X);
                         if (ok || it == 0xFFFFu) {
-                            X = ok ? X : 0.0;
+                            const double Xd = ok ? (double)X : 0.0;
 #pragma unroll
-                            for (int q = 0; q < KW; ++q) dd[q] = q == k ? X : dd[q];
+                            for (int q = 0; q < KW; ++q) dd[q] = q == k ? Xd : dd[q];
                             todo &= todo - 1u;
                             it = 0;
                         } else {
@@ -943,8 +966,10 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     P.G = num_games; P.S = S; P.C = C; P.goal = cfg->goal;
     P.sims = cfg->simulation_per_step; P.upper = cfg->upper_simulation_per_step;
     P.training = training ? 1 : 0; P.mode = mode; P.max_ply = C;
-    P.budget = AF_DEFAULT_TICK_BUDGET;
+    P.budget = AF_DEFAULT_TICK_BUDGET; P.budget_hard = AF_DEFAULT_TICK_BUDGET_HARD;
     if (const char* b = getenv("AF_TICK_BUDGET")) { const int v = atoi(b); if (v > 0) P.budget = v; }
+    if (const char* b = getenv("AF_TICK_BUDGET_HARD")) { const int v = atoi(b); if (v > 0) P.budget_hard = v; }
+    if (P.budget_hard < P.budget) P.budget_hard = P.budget;
     if (node_cap <= 0) node_cap = mode == AF_MODE_SELFPLAY ? 4 * P.sims + 64 : 32768;
     if (node_cap < P.sims + 8) node_cap = P.sims + 8;
     P.node_cap = node_cap;
@@ -1172,6 +1197,7 @@ int af_engine_tick_histogram(af_engine* e, void* stream, uint64_t* out, int32_t 
 int af_engine_set_tick_budget(af_engine* e, int32_t selects_per_launch) {
     if (!e || selects_per_launch < 1) return AF_ERR_ARG;
     e->P.budget = selects_per_launch;
+    if (e->P.budget_hard < selects_per_launch) e->P.budget_hard = selects_per_launch;
     return AF_OK;
 }
 

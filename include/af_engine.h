@@ -45,6 +45,8 @@ extern "C" {
 /* selects a game may do in one launch before it yields at the next simulation boundary (a launch lasts as long
  * as its slowest game; simulations that end in terminal positions never park).  Results do not depend on it. */
 #define AF_DEFAULT_TICK_BUDGET 8
+/* hard cap: past this many selects in one launch a game yields even inside a simulation (AF_TICK_BUDGET_HARD) */
+#define AF_DEFAULT_TICK_BUDGET_HARD 12
 
 /* error codes */
 #define AF_OK 0

@@ -9,7 +9,7 @@
  * (select counter, episode, stream|cell, iteration).  The sampling ALGORITHMS
  * are the reference's (numpy legacy gamma-rejection for Dirichlet(alpha<1),
  * uniform index draws, inverse-cdf move sampling); only the uniform source and
- * the log/exp implementation are the build's own.
+ * the log/exp implementation (and, for the Dirichlet noise, their fp32 precision) are the build's own.
  *
  * Everything in this header is written with plain IEEE-754 +,-,*,/ (no fma, no
  * libm) so that gcc on the host and hipcc on gfx950 produce bit-identical
@@ -139,33 +139,80 @@ AF_HD float af_powf(float x, float y) {
 
 /* ---- samplers ---- */
 
-/* One round of numpy legacy_standard_gamma's rejection loop for alpha < 1 (restated in
- * SURVEY.md §8a): U, V = Exp(1) from the four words r; returns 1 and *x when the candidate is
- * accepted.  Written without data-dependent branches so that a 64-lane wavefront runs every
- * round in lockstep: both arms share one pow, the second arm's log is evaluated for all
- * (its argument (1-U)/alpha is >= 1 in the first arm) and V + 0.0 == V in the first arm. */
-AF_HD int af_gamma_round(double alpha, double inv_a, double one_m_a, af_u32x4 r, double* x) {
-    const double U = af_u53(r.v[0], r.v[1]);
-    const double V = -af_log(1.0 - af_u53(r.v[2], r.v[3]));
-    const double Yl = -af_log((1.0 - U) / alpha);
+/* ---- fp32 plain-op log / exp: the arithmetic of the gamma sampler ----
+ * The Dirichlet noise only perturbs priors (player.py:247-253), so the sampler runs in fp32: half the polynomial
+ * length of the fp64 pair above and no fp64 division — it is ~70 % of a select's instructions on the GPU.
+ * FreeBSD msun e_logf.c / e_expf.c restated with plain +,-,*,/ (no fma): < 2 ulp, bit-identical under gcc and hipcc. */
+AF_HD float af_bits2f(uint32_t u) { union { uint32_t u; float f; } x; x.u = u; return x.f; }
+AF_HD uint32_t af_f2bits(float f) { union { uint32_t u; float f; } x; x.f = f; return x.u; }
+
+#define AF_NEG_HUGE_F (-1.0e30f)
+
+/* natural log of a positive normal float; af_logf(x <= 0) = AF_NEG_HUGE_F (arguments here are >= 2^-24) */
+AF_HD float af_logf(float x) {
+    if (!(x > 0.0f)) return AF_NEG_HUGE_F;
+    const uint32_t b = af_f2bits(x);
+    int e = (int)(b >> 23) - 127;
+    float m = af_bits2f((b & 0x007FFFFFu) | 0x3F800000u);      /* [1,2) */
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }              /* [0.7071,1.4142] */
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * (0.40000972152f + w * 0.24279078841f);
+    const float t2 = z * (0.66666662693f + w * 0.28498786688f);
+    const float R = t2 + t1;
+    const float hfsq = 0.5f * f * f;
+    const float dk = (float)e;
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+/* exp(x); 0 below -87, saturates above 88 */
+AF_HD float af_expf(float x) {
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float inv_ln2 = 1.4426950216e+00f, ln2_hi = 6.9314575195e-01f, ln2_lo = 1.4286067653e-06f;
+    const float kf = x * inv_ln2;
+    const int k = (int)(kf + (kf < 0.0f ? -0.5f : 0.5f));
+    const float dk = (float)k;
+    const float hi = x - dk * ln2_hi, lo = dk * ln2_lo;
+    const float r = hi - lo;
+    const float t = r * r;
+    const float c = r - t * (1.6666625440e-01f + t * -2.7667332906e-03f);
+    const float y = 1.0f - ((lo - (r * c) / (2.0f - c)) - hi);
+    return y * af_bits2f((uint32_t)(k + 127) << 23);            /* k in [-126, 127] */
+}
+
+/* 24-bit uniform in [0, 1 - 2^-24] from one word */
+AF_HD float af_u24(uint32_t a) { return (float)(a >> 8) * 5.9604644775390625e-08f; }
+
+/* One round of numpy legacy_standard_gamma's rejection loop for alpha < 1 (restated in SURVEY.md §8a) on two
+ * words (U, and V = Exp(1)); returns 1 and *x when the candidate is accepted.  Written without data-dependent
+ * branches so that a 64-lane wavefront runs every round in lockstep: both arms share one pow, the second arm's log is
+ * evaluated for all (its argument (1-U)/alpha is >= 1 in the first arm) and V + 0 == V in the first arm. */
+AF_HD int af_gamma_round(float alpha, float inv_a, float one_m_a, uint32_t wu, uint32_t wv, float* x) {
+    const float U = af_u24(wu);
+    const float V = -af_logf(1.0f - af_u24(wv));
+    const float Yl = -af_logf((1.0f - U) * inv_a);
     const int first = U <= one_m_a;
-    const double Y = first ? 0.0 : Yl;
-    const double base = first ? U : one_m_a + alpha * Yl;
-    const double X = af_pow(base, inv_a);
+    const float Y = first ? 0.0f : Yl;
+    const float base = first ? U : one_m_a + alpha * Yl;
+    const float X = af_expf(inv_a * af_logf(base));             /* base == 0 -> exp(-huge) = 0 */
     *x = X;
     return X <= V + Y;
 }
 
-/* One Gamma(alpha,1) variate, alpha < 1: rounds it = 0,1,... until one accepts; uniforms taken
- * from Philox(counter = (sel, episode, GAMMA<<24|cell, round)). */
+/* One Gamma(alpha,1) variate, alpha < 1: rounds it = 0,1,... until one accepts.  Round `it` takes words
+ * 2*(it&1), 2*(it&1)+1 of Philox(counter = (sel, episode, GAMMA<<24|cell, it>>1)): one block feeds two rounds. */
 AF_HD double af_gamma_lt1(double alpha, uint32_t sel, uint32_t episode, uint32_t cell,
                           uint32_t k0, uint32_t k1) {
-    const double inv_a = 1.0 / alpha;
-    const double one_m_a = 1.0 - alpha;
+    const float a = (float)alpha, inv_a = 1.0f / a, one_m_a = 1.0f - a;
+    af_u32x4 r;
     for (uint32_t it = 0;; ++it) {
-        double X;
-        if (af_gamma_round(alpha, inv_a, one_m_a,
-                           af_philox4x32(sel, episode, (AF_STREAM_GAMMA << 24) | cell, it, k0, k1), &X)) return X;
+        if ((it & 1u) == 0u) r = af_philox4x32(sel, episode, (AF_STREAM_GAMMA << 24) | cell, it >> 1, k0, k1);
+        float X;
+        if (af_gamma_round(a, inv_a, one_m_a, r.v[2 * (it & 1u)], r.v[2 * (it & 1u) + 1], &X)) return (double)X;
         if (it == 0xFFFFu) return 0.0;   /* unreachable in practice; bounds the loop */
     }
 }

@@ -93,6 +93,10 @@ def lib():
         L.afo_exp.argtypes = [C.c_double]
         L.afo_powf.restype = C.c_float
         L.afo_powf.argtypes = [C.c_float, C.c_float]
+        L.afo_logf.restype = C.c_float
+        L.afo_logf.argtypes = [C.c_float]
+        L.afo_expf.restype = C.c_float
+        L.afo_expf.argtypes = [C.c_float]
         L.afo_philox.argtypes = [u32p, u32p, u32p]
         _lib = L
     return _lib

@@ -653,6 +653,8 @@ void afo_np_dirichlet(afo_player* P, double alpha, int L, double* out) { mt_diri
 double afo_log(double x) { return af_log(x); }
 double afo_exp(double x) { return af_exp(x); }
 float afo_powf(float x, float y) { return af_powf(x, y); }
+float afo_logf(float x) { return af_logf(x); }
+float afo_expf(float x) { return af_expf(x); }
 void afo_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
     af_u32x4 r = af_philox4x32(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
     memcpy(out, r.v, 16);

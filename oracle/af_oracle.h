@@ -98,6 +98,8 @@ void afo_noise_philox_dirichlet(double alpha, const uint64_t* legal_bb, int C, u
 double afo_log(double x);
 double afo_exp(double x);
 float  afo_powf(float x, float y);
+float  afo_logf(float x);
+float  afo_expf(float x);
 void   afo_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out);
 
 #ifdef __cplusplus

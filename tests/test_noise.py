@@ -45,6 +45,26 @@ def test_log_exp_accuracy():
             2e-7 * float(np.float32(x)) ** float(np.float32(y)) + 1e-45
 
 
+def test_fp32_log_exp_of_the_gamma_sampler():
+    """af_logf / af_expf (plain-op restatements of msun's e_logf / e_expf): within 2 ulp of the correctly rounded result
+    over the ranges the sampler uses them on."""
+    L = oracle.lib()
+    rng = np.random.RandomState(2)
+    xs = np.concatenate([rng.rand(3000), 2.0 ** rng.uniform(-24, 4, 3000), [1.0, 0.5, 2.0, 2.0 ** -24, 3.3333333]]).astype(np.float32)
+    for x in xs:
+        if x <= 0:
+            continue
+        ref = math.log(float(x))
+        got = L.afo_logf(float(x))
+        assert abs(got - ref) <= 2.5 * float(np.spacing(np.float32(abs(ref)))) + 1e-9, (x, got, ref)
+    assert L.afo_logf(1.0) == 0.0 and L.afo_expf(0.0) == 1.0 and L.afo_logf(0.0) < -1e29
+    for x in np.concatenate([rng.uniform(-87, 10, 3000), rng.uniform(-1, 1, 1000)]).astype(np.float32):
+        ref = math.exp(float(x))
+        got = L.afo_expf(float(x))
+        assert abs(got - ref) <= 2.5 * float(np.spacing(np.float32(ref))), (x, got, ref)
+    assert L.afo_expf(-100.0) == 0.0
+
+
 def test_philox_dirichlet_distribution():
     Cc = 121
     legal = np.zeros(4, np.uint64)
