@@ -13,7 +13,7 @@
 // (rows back to back, 11 zero units above, 12 below; the zeros are never written).  A 32-channel slab is 18,432
 // contiguous bytes.
 //
-// Kernel af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC>: NSM 32-channel slabs of the 3x3 input, NSP slabs of the block input
+// Kernel af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ>: NSM 32-channel slabs of the 3x3 input, NSP slabs of the block input
 // whose 1x1 projection is folded in as extra k-steps.  Weight-stationary and persistent: a workgroup = 4 waves (one per
 // SIMD, 512 registers) = CT cout tiles of 32 x KS halves of every 32-channel slab (k-split: wave ks takes channels
 // 16ks..16ks+15) x PS pixel groups (4/PS tiles of 32 pixels); each wave keeps ALL its weight fragments (hi and lo) in
@@ -75,11 +75,17 @@ struct F16sArgs {
     char* out;            // S32, COUT/32 slabs per position
     float* out32;         // OUT32: fp32 [position][COUT][PP] padded planes (the head kernels' input)
     float inv_scale;      // 1 / weight scale
+    // PJ = 1 (producer): this conv1 kernel also computes the block's 1x1 projection of ITS OWN input (the same slabs are in
+    // LDS anyway) and writes it, fp32, in accumulator layout; PJ = 2 (consumer): the conv2 kernel adds it in its epilogue
+    // instead of streaming the block input a second time.  pbuf: [position][cout tile][pixel tile][4][64 lanes] float4.
+    const uint4* pw;      // PJ = 1: projection A fragments [cout tile][ks][2 * NSM * C16][64]
+    float* pbuf;
+    float inv_scale_p;
     int batch, WP, PP;
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
 };
 
-template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC>
+template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_conv_f16s(F16sArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 4 / PS;                    // pixel tiles per wave
@@ -89,6 +95,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     constexpr int SPP = NSP + NSM;                // slabs per position
     constexpr int NFIN = NT / KS;                 // tiles a wave finishes (epilogue) after the k-split exchange
     static_assert(CT * KS * PS == 4 && NT >= KS, "4 waves");
+    static_assert(PJ == 0 || NSP == 0, "a producer / consumer of the separate projection has no projection slabs");
+    constexpr int NPW = PJ == 1 ? NSM * C16 : 0;  // projection items (centre tap of every k-step)
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ct = wv % CT, ks = (wv / CT) % KS, ps = wv / (CT * KS);
@@ -144,6 +152,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             __builtin_memcpy(&W[f], &v, 16);
         }
     }
+    h8 PW[PJ == 1 ? 2 * NPW : 1];
+    if (PJ == 1) {
+        const uint4* wp = A.pw + ((size_t)(ctg * KS + ks) * (2 * NPW)) * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < 2 * NPW; ++f) {
+            const uint4 v = wp[f * 64];
+            __builtin_memcpy(&PW[f], &v, 16);
+        }
+    }
     // lane geometry per pixel tile: LDS byte base of tap (0,0) in slot 0, zero-region twin, output unit
     uint32_t lb[NT], zb[NT];
     int pix[NT];
@@ -162,6 +179,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
 #pragma unroll
     for (int f = 0; f < 2 * NIT; ++f) asm volatile("" : "+v"(W[f]));      // pin the weight loads before the loop (see af_tower_bf16.hip)
+    if (PJ == 1) {
+#pragma unroll
+        for (int f = 0; f < 2 * NPW; ++f) asm volatile("" : "+v"(PW[f]));
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -197,11 +218,22 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // XACC: the cross terms (W_hi*X_lo, W_lo*X_hi; 2^-11 of the main term) get their own accumulator, so the main
         // accumulator is rounded once per item instead of three times (the MFMA's fp32 accumulation is where this path
         // loses accuracy); used where the register budget allows it
-        f32x16 acc[NT], acx[XACC ? NT : 1];
+        f32x16 acc[NT], acx[XACC ? NT : 1], pac[PJ == 1 ? NT : 1];
 #pragma unroll
         for (int jj = 0; jj < NT; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[jj][r] = 0.0f; if (XACC) acx[jj][r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) { acc[jj][r] = 0.0f; if (XACC) acx[jj][r] = 0.0f; if (PJ == 1) pac[jj][r] = 0.0f; }
+        // consumer: this wave's share of the separately computed projection (issued now, used in the epilogue)
+        f32x4 padd[PJ == 2 ? NFIN : 1][4];
+        if (PJ == 2) {
+#pragma unroll
+            for (int jf = 0; jf < NFIN; ++jf) {
+                const int tile = ps * NT + (KS == 2 ? ks * NFIN : 0) + jf;
+                const f32x4* src = reinterpret_cast<const f32x4*>(A.pbuf) + ((((size_t)pos * nso + ctg) * 4 + tile) * 4) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) padd[jf][q] = src[q * 64];
+            }
+        }
 
 #pragma clang loop unroll(full)
         for (int j = 0; j < SPP; ++j) {
@@ -265,6 +297,16 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                     for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fr[b][jj][0], acc[jj], 0, 0, 0);
                 }
+                if (PJ == 1 && !proj && it % 9 == 4) {                     // centre tap: the 1x1 projection reads the very same fragments
+                    const int pi = (j - NSP) * C16 + it / 9;
+                    const h8 ph = PW[2 * pi], pl = PW[2 * pi + 1];
+#pragma unroll
+                    for (int jj = 0; jj < NT; ++jj) pac[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, fr[b][jj][0], pac[jj], 0, 0, 0);
+#pragma unroll
+                    for (int jj = 0; jj < NT; ++jj) pac[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, fr[b][jj][1], pac[jj], 0, 0, 0);
+#pragma unroll
+                    for (int jj = 0; jj < NT; ++jj) pac[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, fr[b][jj][0], pac[jj], 0, 0, 0);
+                }
 #pragma unroll
                 for (int q = 0; q < 2 * NT; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -296,30 +338,51 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[jj][r] += acx[jj][r];
         }
-        // k-split: the two waves of a pair exchange the halves they do not finish
+        // k-split: the two waves of a pair exchange the halves they do not finish (accumulators, and the projection's)
+#define AF_EXCHANGE(ACC, SCR)                                                                                              \
+    {                                                                                                                      \
+        _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                                \
+            if ((jj / NFIN) != ks) {                                                                                       \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
+                    f32x4 v = {ACC[jj][4 * q], ACC[jj][4 * q + 1], ACC[jj][4 * q + 2], ACC[jj][4 * q + 3]};                \
+                    *reinterpret_cast<f32x4*>((SCR) + (uint32_t)(jj * 4 + q) * 1024u + lane * 16u) = v;                    \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
+#define AF_COMBINE(ACC, SCR)                                                                                               \
+    {                                                                                                                      \
+        _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                                \
+            if ((jj / NFIN) == ks) {                                                                                       \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
+                    const f32x4 v = *reinterpret_cast<const f32x4*>((SCR) + (uint32_t)(jj * 4 + q) * 1024u + lane * 16u);  \
+                    ACC[jj][4 * q] += v[0]; ACC[jj][4 * q + 1] += v[1]; ACC[jj][4 * q + 2] += v[2]; ACC[jj][4 * q + 3] += v[3]; \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
         if (KS == 2) {
             char* scr = smem + kScrOff + (uint32_t)(ct + CT * ps) * (NT * 4096u);
-#pragma unroll
-            for (int jj = 0; jj < NT; ++jj) {
-                const bool mine = (jj / NFIN) == ks;
-                if (!mine) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v = {acc[jj][4 * q], acc[jj][4 * q + 1], acc[jj][4 * q + 2], acc[jj][4 * q + 3]};
-                        *reinterpret_cast<f32x4*>(scr + (uint32_t)(jj * 4 + q) * 1024u + lane * 16u) = v;
-                    }
-                }
-            }
+            char* scp = scr + (uint32_t)(CT * PS) * (NT * 4096u);
+            AF_EXCHANGE(acc, scr)
+            if (PJ == 1) AF_EXCHANGE(pac, scp)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            AF_COMBINE(acc, scr)
+            if (PJ == 1) AF_COMBINE(pac, scp)
+        }
+#undef AF_EXCHANGE
+#undef AF_COMBINE
+        if (PJ == 1) {                                                       // the projection, fp32, in accumulator layout
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
-                const bool mine = (jj / NFIN) == ks;
-                if (mine) {
+                if (KS == 2 && (jj / NFIN) != ks) continue;
+                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)pos * nso + ctg) * 4 + ps * NT + jj) * 4) * 64 + lane;
+                if (!(A.abl & 2)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(scr + (uint32_t)(jj * 4 + q) * 1024u + lane * 16u);
-                        acc[jj][4 * q] += v[0]; acc[jj][4 * q + 1] += v[1]; acc[jj][4 * q + 2] += v[2]; acc[jj][4 * q + 3] += v[3];
+                        f32x4 v = {pac[jj][4 * q] * A.inv_scale_p, pac[jj][4 * q + 1] * A.inv_scale_p, pac[jj][4 * q + 2] * A.inv_scale_p, pac[jj][4 * q + 3] * A.inv_scale_p};
+                        dst[q * 64] = v;
                     }
                 }
             }
@@ -339,7 +402,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             if (!mine) continue;
             float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = elu1(acc[jj][r] * A.inv_scale + bs[r]);
+            for (int r = 0; r < 16; ++r) {
+                float pre = acc[jj][r] * A.inv_scale + bs[r];
+                if (PJ == 2) pre += padd[jj % NFIN][r / 4][r % 4];       // (a wave's own tiles are jj / NFIN == ks)
+                v[r] = elu1(pre);
+            }
             if (OUT32) {
                 const int y = pix[jj] / kS, x = pix[jj] - y * kS;
                 float* o = A.out32 + ((size_t)pos * (nso * 32) + 32 * ctg + 16 * kg) * A.PP + (y + 1) * A.WP + x + 1;
@@ -420,14 +487,17 @@ __global__ __launch_bounds__(256) void af_stem_f16s(const float* __restrict__ pl
 }
 
 // ------------------------------------------------------------------ host ------------------------------------------------------------------
-struct LayerCfg { int cin, cout, pcin, CT, KS, PS, gy; };
-// block b: conv1 = layer 2b, conv2 (+ projection) = layer 2b+1
+struct LayerCfg { int cin, cout, pcin, CT, KS, PS, gy, pj; };
+// block b: conv1 = layer 2b, conv2 (+ projection) = layer 2b+1.  pcin: channels of the projection input folded into this
+// layer as extra k-steps; pj: 1 = this conv1 also produces the block's projection (from its own input), 2 = this conv2
+// adds the produced projection (blocks 3 and 5: their block input is 4x / 2x wider than the block, so streaming it
+// again for a 1x1 convolution costs more HBM time than the layer's own work)
 const LayerCfg kLayers[10] = {
-    {32, 64, 0, 2, 1, 2, 1},   {64, 64, 32, 2, 1, 2, 1},      // bone/block1
-    {64, 128, 0, 4, 1, 1, 1},  {128, 128, 64, 2, 2, 1, 2},    // bone/block2
-    {128, 32, 0, 1, 2, 2, 1},  {32, 32, 128, 1, 2, 2, 1},     // value/block3
-    {128, 64, 0, 2, 2, 1, 1},  {64, 64, 128, 2, 2, 1, 1},     // policy/block4
-    {64, 32, 0, 1, 2, 2, 1},   {32, 32, 64, 1, 2, 2, 1},      // policy/block5
+    {32, 64, 0, 2, 1, 2, 1, 0},   {64, 64, 32, 2, 1, 2, 1, 0},      // bone/block1
+    {64, 128, 0, 4, 1, 1, 1, 0},  {128, 128, 64, 2, 2, 1, 2, 0},    // bone/block2
+    {128, 32, 0, 1, 2, 2, 1, 1},  {32, 32, 0, 1, 2, 2, 1, 2},       // value/block3
+    {128, 64, 0, 2, 2, 1, 1, 0},  {64, 64, 128, 2, 2, 1, 1, 0},     // policy/block4
+    {64, 32, 0, 1, 2, 2, 1, 1},   {32, 32, 0, 1, 2, 2, 1, 2},       // policy/block5
 };
 const char* const kBlockNames[5] = {"bone/block1", "bone/block2", "value/block3", "policy/block4", "policy/block5"};
 
@@ -475,6 +545,31 @@ std::vector<_Float16> pack_layer(const LayerCfg& L, const float* w3, const float
     return out;
 }
 
+// A fragments of a separately produced 1x1 projection (producer layer L: its own cin -> `cout` couts): [cout tile][ks][item]
+// [hi|lo][lane][8], one item per (slab, 16-channel k-step), in the producer's order.  w1: [cin][cout].
+std::vector<_Float16> pack_proj(const LayerCfg& L, int cout, const float* w1, float scale) {
+    const int NSM = L.cin / 32, C16 = 2 / L.KS, NPW = NSM * C16, tiles = cout / 32;
+    std::vector<_Float16> out((size_t)tiles * L.KS * 2 * NPW * 64 * 8);
+    for (int tile = 0; tile < tiles; ++tile)
+        for (int ks = 0; ks < L.KS; ++ks)
+            for (int s = 0; s < NSM; ++s)
+                for (int c = 0; c < C16; ++c) {
+                    const int item = s * C16 + c, c16 = L.KS == 2 ? ks : c;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int m = lane & 31;
+                            const int co = 32 * tile + 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3);
+                            const int ci = 32 * s + 16 * c16 + 8 * (lane >> 5) + e;
+                            const float v = w1[(size_t)ci * cout + co] * scale;
+                            const _Float16 h = (_Float16)v;
+                            const size_t base = ((((size_t)(tile * L.KS + ks) * NPW + item) * 2) * 64 + lane) * 8 + e;
+                            out[base] = h;
+                            out[base + 64 * 8] = (_Float16)(v - (float)h);
+                        }
+                }
+    return out;
+}
+
 float pick_scale(const std::vector<float>& a, const std::vector<float>* b) {
     float mx = 0.0f;
     for (float v : a) mx = std::max(mx, std::fabs(v));
@@ -485,18 +580,18 @@ float pick_scale(const std::vector<float>& a, const std::vector<float>* b) {
     return std::ldexp(1.0f, 13 - e);        // mx * scale in [4096, 8192): 8x below the fp16 maximum
 }
 
-template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC>
+template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ = 0>
 int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     constexpr int NT = 4 / PS;
-    const size_t lds = kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 : 0);
+    const size_t lds = kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 * (PJ == 1 ? 2 : 1) : 0);
     static bool attr = false;
     if (!attr) {
-        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC>),
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     const int gx = std::max(1, std::min(a.batch, ncu / gy));
-    hipLaunchKernelGGL((af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC>), dim3(gx, gy), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ>), dim3(gx, gy), dim3(256), lds, st, a);
     return 0;
 }
 
@@ -507,8 +602,10 @@ struct f16s_net {
     std::vector<void*> allocs;
     float *stem_w = nullptr, *stem_b = nullptr;
     uint4* w[10] = {};
+    uint4* pw[10] = {};           // producer layers: the block's projection weights
+    float* pbuf[5] = {};          // blocks with a separately produced projection: fp32, accumulator layout
     float* bias[10] = {};
-    float inv_scale[10] = {};
+    float inv_scale[10] = {}, inv_scale_p[10] = {};
     // S32 activations: f0, then per block g (conv1 output) and o (block output; blocks 2 and 4 end in fp32 planes)
     char *f0 = nullptr, *g[5] = {}, *o[5] = {};
     int abl = 0;
@@ -527,9 +624,19 @@ int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::s
         const std::string s = kBlockNames[b];
         const std::vector<float>&k1 = get(s + "_conv1/kernel"), &k2 = get(s + "_conv2/kernel"), &kr = get(s + "_res/kernel");
         const LayerCfg &L1 = kLayers[2 * b], &L2 = kLayers[2 * b + 1];
-        const float s1 = pick_scale(k1, nullptr), s2 = pick_scale(k2, &kr);
+        const bool split_proj = L1.pj == 1;
+        const float s1 = pick_scale(k1, nullptr), s2 = pick_scale(k2, split_proj ? nullptr : &kr);
         const std::vector<_Float16> p1 = pack_layer(L1, k1.data(), nullptr, s1), p2 = pack_layer(L2, k2.data(), kr.data(), s2);
         rc = dev_upload(n->allocs, &n->w[2 * b], p1.data(), p1.size() * 2);
+        if (!rc && split_proj) {
+            const float sp = pick_scale(kr, nullptr);
+            const std::vector<_Float16> pp = pack_proj(L1, L2.cout, kr.data(), sp);
+            rc = dev_upload(n->allocs, &n->pw[2 * b], pp.data(), pp.size() * 2);
+            n->inv_scale_p[2 * b] = 1.0f / sp;
+            void* q = nullptr;
+            const size_t bytes = (size_t)max_batch * (L2.cout / 32) * 4 * 4 * 64 * 16;
+            if (!rc) { FS_HIP_OK(hipMalloc(&q, bytes)); n->allocs.push_back(q); n->pbuf[b] = (float*)q; }
+        }
 
         if (!rc) rc = dev_upload(n->allocs, &n->w[2 * b + 1], p2.data(), p2.size() * 2);
         std::vector<float> bsum(get(s + "_conv2/bias"));
@@ -571,18 +678,19 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
     F16sArgs a;
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
     a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = n->abl;
+    a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
     switch (li) {
         // <NSM, NSP, CT, KS, PS, OUT32, XACC>: XACC wherever weights + 2 x accumulators + fragments fit 512 registers
         case 0: return launch_cfg<1, 0, 2, 1, 2, false, true>(st, a, 1, n->ncu);
         case 1: return launch_cfg<2, 1, 2, 1, 2, false, true>(st, a, 1, n->ncu);
         case 2: return launch_cfg<2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
         case 3: return launch_cfg<4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
-        case 4: return launch_cfg<4, 0, 1, 2, 2, false, true>(st, a, 1, n->ncu);
-        case 5: return launch_cfg<1, 4, 1, 2, 2, true, true>(st, a, 1, n->ncu);
+        case 4: return launch_cfg<4, 0, 1, 2, 2, false, false, 1>(st, a, 1, n->ncu);   // (no XACC: weights + projection weights + 3 accumulator sets would spill)
+        case 5: return launch_cfg<1, 0, 1, 2, 2, true, true, 2>(st, a, 1, n->ncu);
         case 6: return launch_cfg<4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
         case 7: return launch_cfg<2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
-        case 8: return launch_cfg<2, 0, 1, 2, 2, false, true>(st, a, 1, n->ncu);
-        default: return launch_cfg<1, 2, 1, 2, 2, true, true>(st, a, 1, n->ncu);
+        case 8: return launch_cfg<2, 0, 1, 2, 2, false, true, 1>(st, a, 1, n->ncu);
+        default: return launch_cfg<1, 0, 1, 2, 2, true, true, 2>(st, a, 1, n->ncu);
     }
 }
 

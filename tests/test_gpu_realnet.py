@@ -113,7 +113,8 @@ def _rand_planes(B, S, seed):
     return x
 
 
-def test_deep_bf16_tower_kernel_matches_fp32_reference():
+@pytest.mark.parametrize("blocks", [3, 8])
+def test_deep_bf16_tower_kernel_matches_fp32_reference(blocks):
     """af_tower_forward (hand-written bf16 MFMA tower, BASELINE configs[4]) against an fp32 PyTorch evaluation of the
     same bf16 weights with the activations rounded to bf16 at the same points (after each ELU).  Bar: the kernel's error
     must not exceed the error of the all-PyTorch bf16 path it replaces (bf16 keeps 8 mantissa bits; no bit parity)."""
@@ -121,7 +122,7 @@ def test_deep_bf16_tower_kernel_matches_fp32_reference():
     import torch.nn.functional as F
     from alphafive_amd.network_deep import DeepResNet
     B = 300                                          # more than one pass of the 256 persistent workgroups, ragged tail
-    net = DeepResNet(11, blocks=3, width=128, device="cuda", seed=3)
+    net = DeepResNet(11, blocks=blocks, width=128, device="cuda", seed=3)      # 8 = BASELINE configs[4]'s depth
     g = torch.Generator().manual_seed(5)
     for blk in net.tower:                            # non-zero biases
         for k in ("res", "c1", "c2"):
@@ -216,3 +217,30 @@ def test_player_pipe_mode_through_networkapi_matches_pv_fn_mode():
     a.close()
     b.close()
     net.close()
+
+
+def test_config5_full_size_8192_games_on_the_bf16_tower():
+    """BASELINE configs[4] at its own size: 8192 concurrent games on the hand-written bf16 tower for more than one full
+    ply (performance-only configuration: no bit parity for the net, but the tree side is the same bit-exact engine, so the
+    bookkeeping invariants must hold and the evaluator must stay a probability distribution on all 8192 leaves)."""
+    import torch
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.network_deep import DeepResNet
+    G = 8192
+    net = DeepResNet(11, blocks=8, width=128, device="cuda")
+    pv = net.select_backend("hip", G)
+    cfg = make_cfg(simulation_per_step=60, upper_simulation_per_step=80)
+    sp = SelfPlayEngine(cfg, G, pv, device=0, seed=6)
+    sp.run_ticks(150)                                 # 60 sims -> first move, 60 -> second, 30 into the third
+    sp.check()
+    ct = sp.counters()
+    assert ct["plies"] == 2 * G and ct["sims"] == ct["expands"] + ct["terminals"] and ct["sims"] >= 148 * G
+    p, v = pv(sp.planes)
+    assert p.shape == (G, 121) and torch.isfinite(p).all() and torch.isfinite(v).all()
+    assert (p.sum(1) - 1).abs().max().item() < 1e-3 and v.abs().max().item() <= 1.0
+    # the hand-written path and the all-PyTorch bf16 path agree to bf16 accuracy on the very leaves of this batch
+    p2, v2 = net.eval_device(sp.planes)
+    assert (p - p2).abs().max().item() < 0.05 and (v - v2).abs().max().item() < 0.1
+    d = sp.engine.tree_dump(G - 1)
+    assert ((d["sum_n"] - d["n"].sum(1) >= 0) & (d["sum_n"] - d["n"].sum(1) <= 1)).all()
+    sp.close()
