@@ -59,7 +59,8 @@ int af_tower_heads(af_tower* t, void* stream, const void* x_dev, void* vin_dev, 
 
 /* A/B knobs (process-global): key 0 = B-fragment ring depth (0 = per-kernel default, 8, 12, 16), key 1 = persistent
  * workgroups (0 = one per CU), key 2 = profiling ablation bits (results wrong by design: 1 no re-staging, 2 no stores,
- * 8 no LDS reads). */
+ * 8 no LDS reads), key 3 = convolution kernel (0 af_tower_conv = default, 1 af_tower_conv2: the slab-ring structure of
+ * af_conv_f16s.hip with two cout tiles per wave — correct, measured 5 % slower). */
 int af_tower_tune(int32_t key, int32_t value);
 
 int64_t af_tower_flops_per_position(const af_tower* t);   /* 2*MAC of the tower, direct convolution */
