@@ -195,7 +195,7 @@ __device__ int terminal_test(const EngineParams& P, const u64* mine, const u64* 
 }
 
 template <int KW>
-__device__ __forceinline__ uint32_t key_hash(const u64* mine, const u64* theirs) {
+__host__ __device__ __forceinline__ uint32_t key_hash(const u64* mine, const u64* theirs) {
     u64 h = 0x9E3779B97F4A7C15ull;
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
@@ -1245,6 +1245,55 @@ int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys,
         ++o;
     }
     return live;
+}
+
+// Player.reset(search_tree) (player.py:48-51): adopt a tree handed over by the caller — replaces game `game`'s store by the
+// `count` nodes given in tree_dump's format (keys [count][2KW]; sum_n [count]; n, w, p [count][C] by cell; f32 [count][C] =
+// "W is fp32-typed", SURVEY rule 2).  EXTERNAL mode, between moves.
+int af_engine_load_tree(af_engine* e, int32_t game, int32_t count, const uint64_t* keys, const int32_t* sum_n, const int32_t* n,
+                        const float* w, const float* p, const uint8_t* f32) {
+    if (!e || game < 0 || game >= e->P.G || e->P.mode != AF_MODE_EXTERNAL || count < 0 || count > e->P.node_cap) return AF_ERR_ARG;
+    if (count > 0 && (!keys || !sum_n || !n || !w || !p || !f32)) return AF_ERR_ARG;
+    EngineParams& P = e->P;
+    const int KW = e->KW, KW2 = 2 * KW, CP = 64 * KW, C = P.C;
+    const size_t hcap = (size_t)P.hash_mask + 1, nb = (size_t)game * P.node_cap;
+    std::vector<uint32_t> slots(hcap, 0u);
+    std::vector<int32_t> bn((size_t)count * CP, 0);
+    std::vector<float> bw((size_t)count * CP, 0.0f), bp((size_t)count * CP, 0.0f);
+    for (int i = 0; i < count; ++i) {
+        const uint64_t* k = keys + (size_t)i * KW2;
+        for (int q = 0; q < KW; ++q)
+            if (((k[q] | k[KW + q]) & ~P.boardmask[q]) || (k[q] & k[KW + q])) return AF_ERR_ARG;
+        const u64* kk = reinterpret_cast<const u64*>(k);
+        uint32_t h = KW == 2 ? key_hash<2>(kk, kk + KW) : key_hash<4>(kk, kk + KW);
+        for (;;) {
+            h &= P.hash_mask;
+            if (slots[h] == 0u) { slots[h] = (uint32_t)i + 1u; break; }
+            const uint64_t* o = keys + (size_t)(slots[h] - 1u) * KW2;
+            if (memcmp(o, k, (size_t)KW2 * 8) == 0) return AF_ERR_ARG;          // the same position twice
+            ++h;
+        }
+        for (int c = 0; c < C; ++c) {
+            const int32_t nn = n[(size_t)i * C + c];
+            if (nn < 0) return AF_ERR_ARG;
+            bn[(size_t)i * CP + c] = nn | (f32[(size_t)i * C + c] ? (int32_t)0x80000000 : 0);
+            bw[(size_t)i * CP + c] = w[(size_t)i * C + c];
+            bp[(size_t)i * CP + c] = p[(size_t)i * C + c];
+        }
+    }
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(P.hash + (size_t)game * hcap, slots.data(), hcap * 4, hipMemcpyHostToDevice));
+    if (count > 0) {
+        HIP_OK(hipMemcpy(P.node_key + nb * KW2, keys, (size_t)count * KW2 * 8, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(P.node_sum + nb, sum_n, (size_t)count * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(P.edge_n + nb * CP, bn.data(), bn.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(P.edge_w + nb * CP, bw.data(), bw.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(P.edge_p + nb * CP, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    }
+    int32_t zero = 0;
+    HIP_OK(hipMemcpy(P.nodes + game, &count, 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(P.nfree + game, &zero, 4, hipMemcpyHostToDevice));
+    return AF_OK;
 }
 
 // utils.py:178-196 state_to_board, straight into a key

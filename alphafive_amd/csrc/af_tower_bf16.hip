@@ -545,6 +545,115 @@ __global__ __launch_bounds__(256) void af_tower_heads_kernel(HeadsArgs A) {
     }
 }
 
+// af_tower_dense_kernel: the three dense layers and the softmax behind the heads' 1x1 convolutions (network.py:73-76,85-88)
+// for 32 positions per workgroup on the same MFMA: D[out][position] = sum_k W^T[out][k] * in[position][k].
+//   policy: 1936 -> 121 (+ bias) -> softmax: wave w owns outputs 32w..32w+31 (121 padded to 128 with zero weights), 121 k-steps
+//   value : 484 -> 64 (+ bias, ELU) on waves 0 and 1 (31 k-steps, K padded to 496), then 64 -> 1 (+ bias), tanh(x/2)
+// A fragments (weights) are pre-packed [k-step][out tile][lane][8] and stream from L2; a B fragment is 16 bytes of one
+// position's input row per lane, read straight from global memory (consecutive k-steps reuse the same lines).
+struct DenseArgs {
+    const __bf16* vin;    // [B][484]
+    const __bf16* pin;    // [B][1936]
+    const uint4* wp;      // [121][4][64] policy A fragments
+    const uint4* wv;      // [31][2][64] value fc1 A fragments
+    const float* pb;      // [128] policy bias (padded with -inf-like for the 7 dead outputs)
+    const float* vb1;     // [64]
+    const float* vw2;     // [64]
+    float vb2;
+    float* policy;        // fp32 [B][121]
+    float* value;         // fp32 [B]
+    int batch;
+};
+
+__global__ __launch_bounds__(256) void af_tower_dense_kernel(DenseArgs A) {
+    __shared__ float s_red[4][2][32];         // [wave][lane half][position]: partial max / sum / dot
+    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    typedef uint32_t u32x4d __attribute__((ext_vector_type(4)));
+    for (int p0 = blockIdx.x * 32; p0 < A.batch; p0 += gridDim.x * 32) {
+        const int pos = p0 + nn < A.batch ? p0 + nn : A.batch - 1;      // dead lanes of a ragged tail recompute the last position
+        // ---------------- policy ----------------
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const __bf16* prow = A.pin + (size_t)pos * 1936 + 8 * kg;
+        for (int k = 0; k < 121; ++k) {
+            const u32x4d a = *reinterpret_cast<const u32x4d*>(A.wp + ((size_t)k * 4 + wv) * 64 + lane);
+            const u32x4d b = *reinterpret_cast<const u32x4d*>(prow + 16 * k);
+            bf16x8 x, y;
+            __builtin_memcpy(&x, &a, 16);
+            __builtin_memcpy(&y, &b, 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+        }
+        // a lane holds the outputs 32*wv + 16*kg + r of position nn (rows permuted at pack time)
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] += A.pb[32 * wv + 16 * kg + r]; mx = acc[r] > mx ? acc[r] : mx; }
+        s_red[wv][kg][nn] = mx;
+        __syncthreads();
+        float gmx = -3.0e38f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const float v = s_red[w][h][nn]; gmx = v > gmx ? v : gmx; }
+        __syncthreads();
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = __expf(acc[r] - gmx); sum += acc[r]; }
+        s_red[wv][kg][nn] = sum;
+        __syncthreads();
+        float gs = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) gs += s_red[w][h][nn];
+        __syncthreads();
+        const float inv = 1.0f / gs;
+        if (p0 + nn < A.batch) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * wv + 16 * kg + r;
+                if (o < 121) A.policy[(size_t)pos * 121 + o] = acc[r] * inv;
+            }
+        }
+        // ---------------- value ----------------
+        float part = 0.0f;
+        if (wv < 2) {
+            f32x16 av;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) av[r] = 0.0f;
+            const __bf16* vrow = A.vin + (size_t)pos * 484 + 8 * kg;
+            for (int k = 0; k < 31; ++k) {
+                const u32x4d a = *reinterpret_cast<const u32x4d*>(A.wv + ((size_t)k * 2 + wv) * 64 + lane);
+                u32x4d b = {0u, 0u, 0u, 0u};
+                if (16 * k + 8 * kg + 8 <= 484) b = *reinterpret_cast<const u32x4d*>(vrow + 16 * k);
+                else if (16 * k + 8 * kg < 484) {                          // the last, partial 8-group: 484 = 30*16 + 4
+                    __bf16 t8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t8[e] = 16 * k + 8 * kg + e < 484 ? vrow[16 * k + e] : (__bf16)0.0f;
+                    __builtin_memcpy(&b, t8, 16);
+                }
+                bf16x8 x, y;
+                __builtin_memcpy(&x, &a, 16);
+                __builtin_memcpy(&y, &b, 16);
+                av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, av, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * wv + 16 * kg + r;
+                part += elu1(av[r] + A.vb1[o]) * A.vw2[o];
+            }
+        }
+        s_red[wv][kg][nn] = part;
+        __syncthreads();
+        if (wv == 0 && kg == 0 && p0 + nn < A.batch) {
+            const float z = s_red[0][0][nn] + s_red[0][1][nn] + s_red[1][0][nn] + s_red[1][1][nn] + A.vb2;
+            A.value[pos] = tanhf(0.5f * z);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ host ------------------------------------------------------------------
 struct af_tower {
     int S = 0, width = 0, blocks = 0, device = 0;
@@ -555,6 +664,9 @@ struct af_tower {
     float* stem_b = nullptr;
     float* heads_w = nullptr;
     float* heads_b = nullptr;
+    uint4 *dense_wp = nullptr, *dense_wv = nullptr;     // af_tower_dense_kernel: packed policy / value fc1 weights
+    float *dense_pb = nullptr, *dense_vb1 = nullptr, *dense_vw2 = nullptr;
+    float dense_vb2 = 0.0f;
 };
 
 static uint16_t bf16_rne(float f) {
@@ -563,6 +675,13 @@ static uint16_t bf16_rne(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+
+static float bf16_round(float f) {
+    const uint32_t u = (uint32_t)bf16_rne(f) << 16;
+    float r;
+    memcpy(&r, &u, 4);
+    return r;
 }
 
 // A fragments: [wave][s][lane][e] = W[cout = 32*wave + perm(lane&31)][cin = 16*cc + 8*(lane>>5) + e][tap t], s = 8*t + cc;
@@ -672,6 +791,11 @@ void af_tower_destroy(af_tower* t) {
     if (t->stem_b) (void)hipFree(t->stem_b);
     if (t->heads_w) (void)hipFree(t->heads_w);
     if (t->heads_b) (void)hipFree(t->heads_b);
+    if (t->dense_wp) (void)hipFree(t->dense_wp);
+    if (t->dense_wv) (void)hipFree(t->dense_wv);
+    if (t->dense_pb) (void)hipFree(t->dense_pb);
+    if (t->dense_vb1) (void)hipFree(t->dense_vb1);
+    if (t->dense_vw2) (void)hipFree(t->dense_vw2);
     delete t;
 }
 
@@ -693,12 +817,6 @@ int af_tower_set_block(af_tower* t, int32_t b, const float* c1_w, const float* c
     return rc;
 }
 
-static float bf16_round(float f) {
-    const uint32_t u = (uint32_t)bf16_rne(f) << 16;
-    float r;
-    memcpy(&r, &u, 4);
-    return r;
-}
 
 int af_tower_set_stem(af_tower* t, const float* w, const float* b) {
     if (!t || !w || !b) return AF_TOWER_ERR_ARG;
@@ -729,6 +847,53 @@ int af_tower_set_heads(af_tower* t, const float* vconv_w, const float* vconv_b, 
     int rc = upload(&t->heads_w, w.data(), w.size() * 4);
     if (!rc) rc = upload(&t->heads_b, b.data(), b.size() * 4);
     return rc;
+}
+
+// dense layers (network.py:73-76,85): vfc1 [484][64] + [64], vfc2 [64] + [1], pfc [1936][121] + [121], all [in][out] fp32
+int af_tower_set_dense(af_tower* t, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                       const float* pfc_w, const float* pfc_b) {
+    if (!t || !vfc1_w || !vfc1_b || !vfc2_w || !vfc2_b || !pfc_w || !pfc_b) return AF_TOWER_ERR_ARG;
+    TW_HIP_OK(hipSetDevice(t->device));
+    auto perm = [](int m) { return 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3); };
+    std::vector<uint16_t> wp((size_t)121 * 4 * 64 * 8, 0), wv((size_t)31 * 2 * 64 * 8, 0);
+    for (int k = 0; k < 121; ++k)
+        for (int tile = 0; tile < 4; ++tile)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int o = 32 * tile + perm(lane & 31), ki = 16 * k + 8 * (lane >> 5) + e;
+                    if (o < 121) wp[((((size_t)k * 4 + tile) * 64) + lane) * 8 + e] = bf16_rne(pfc_w[(size_t)ki * 121 + o]);
+                }
+    for (int k = 0; k < 31; ++k)
+        for (int tile = 0; tile < 2; ++tile)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int o = 32 * tile + perm(lane & 31), ki = 16 * k + 8 * (lane >> 5) + e;
+                    if (ki < 484) wv[((((size_t)k * 2 + tile) * 64) + lane) * 8 + e] = bf16_rne(vfc1_w[(size_t)ki * 64 + o]);
+                }
+    std::vector<float> pb(128, -1.0e30f), vb1(vfc1_b, vfc1_b + 64), vw2(64);
+    for (int o = 0; o < 121; ++o) pb[o] = bf16_round(pfc_b[o]);
+    for (int o = 0; o < 64; ++o) { vb1[o] = bf16_round(vfc1_b[o]); vw2[o] = bf16_round(vfc2_w[o]); }
+    t->dense_vb2 = bf16_round(vfc2_b[0]);
+    int rc = upload(&t->dense_wp, wp.data(), wp.size() * 2);
+    if (!rc) rc = upload(&t->dense_wv, wv.data(), wv.size() * 2);
+    if (!rc) rc = upload(&t->dense_pb, pb.data(), pb.size() * 4);
+    if (!rc) rc = upload(&t->dense_vb1, vb1.data(), vb1.size() * 4);
+    if (!rc) rc = upload(&t->dense_vw2, vw2.data(), vw2.size() * 4);
+    return rc;
+}
+
+int af_tower_dense(af_tower* t, void* stream, const void* vin_dev, const void* pin_dev, float* policy_dev, float* value_dev,
+                   int32_t batch) {
+    if (!t || !vin_dev || !pin_dev || !policy_dev || !value_dev || batch < 1) return AF_TOWER_ERR_ARG;
+    if (!t->dense_wp) return AF_TOWER_ERR_STATE;
+    DenseArgs a;
+    a.vin = static_cast<const __bf16*>(vin_dev); a.pin = static_cast<const __bf16*>(pin_dev);
+    a.wp = t->dense_wp; a.wv = t->dense_wv; a.pb = t->dense_pb; a.vb1 = t->dense_vb1; a.vw2 = t->dense_vw2; a.vb2 = t->dense_vb2;
+    a.policy = policy_dev; a.value = value_dev; a.batch = batch;
+    const int blocks = (batch + 31) / 32;
+    hipLaunchKernelGGL(af_tower_dense_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    TW_HIP_OK(hipGetLastError());
+    return AF_TOWER_OK;
 }
 
 int af_tower_stem(af_tower* t, void* stream, const float* planes_dev, void* x_dev, int32_t batch) {

@@ -75,6 +75,7 @@ def lib():
         L.af_engine_tick_histogram.argtypes = [vp, vp, u64p, C.c_int32]
         L.af_engine_set_tick_budget.argtypes = [vp, C.c_int32]
         L.af_engine_tree_dump.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
+        L.af_engine_load_tree.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
         L.af_state_to_key.argtypes = [C.c_char_p, C.c_int32, u64p]
         L.af_key_to_state.argtypes = [u64p, C.c_int32, C.c_char_p, C.c_int32]
         _lib = L
@@ -197,6 +198,15 @@ class Engine:
                                              _p(n, C.c_int32), _p(w, C.c_float), _p(p, C.c_float), _p(f, C.c_uint8)),
                    "tree_dump")
         return dict(keys=keys, sum_n=sum_n, n=n, w=w, p=p, f32=f)
+
+    def load_tree(self, game, dump):
+        """Adopt a tree (tree_dump's dict format) as game `game`'s store: Player.reset(search_tree)."""
+        cnt = len(dump["sum_n"])
+        arr = {k: np.ascontiguousarray(dump[k], t) for k, t in (("keys", np.uint64), ("sum_n", np.int32), ("n", np.int32),
+                                                                 ("w", np.float32), ("p", np.float32), ("f32", np.uint8))}
+        _check(lib().af_engine_load_tree(self._h, game, cnt, _p(arr["keys"], C.c_uint64), _p(arr["sum_n"], C.c_int32),
+                                         _p(arr["n"], C.c_int32), _p(arr["w"], C.c_float), _p(arr["p"], C.c_float),
+                                         _p(arr["f32"], C.c_uint8)), "af_engine_load_tree")
 
     def pack_ints(self, max_eps, max_plies):
         return int(_check(lib().af_engine_pack_ints(self._h, max_eps, max_plies), "af_engine_pack_ints"))

@@ -1,8 +1,8 @@
 """BASELINE configs[4]: a deeper policy/value net — N residual blocks of the reference's block type
 (network.py:52-56: 1x1 projection || 3x3+ELU -> 3x3, add, ELU) at constant width, the reference's two heads,
-evaluated in bf16.  The residual tower (99 % of the FLOPs) runs on the hand-written MFMA kernel of
-csrc/af_tower_bf16.hip (`select_backend("hip")`, the bench default), as do the 5x5 stem and the heads' 1x1
-convolutions; only the three small dense layers and the softmax stay on PyTorch-ROCm ops.  `eval_device` is the
+evaluated in bf16.  The whole forward runs on the hand-written MFMA kernels of csrc/af_tower_bf16.hip
+(`select_backend("hip")`, the bench default): 5x5 stem, residual tower (99 % of the FLOPs), the heads' 1x1
+convolutions and the three dense layers + softmax.  `eval_device` is the
 all-PyTorch reference path.  Performance-only configuration (no checkpoint exists for
 it, random init, no bit parity); it plugs into SelfPlayEngine through the same
 planes[G,3,S,S] -> (prob[G,C], value[G]) evaluator seam as the fp32 net.
@@ -10,6 +10,20 @@ planes[G,3,S,S] -> (prob[G,C], value[G]) evaluator seam as the fp32 net.
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+
+class _HipEvaluator(object):
+    """planes -> (prob, value) on the hand-written kernels; bind_outputs lets the engine own the result tensors."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def __call__(self, x):
+        return self.net.eval_hip(x)
+
+    def bind_outputs(self, policy, value):
+        if policy.shape[0] >= self.net._tower.max_batch:
+            self.net._tower.bind_outputs(policy, value)
 
 
 class DeepResNet(object):
@@ -63,13 +77,23 @@ class DeepResNet(object):
             raise ValueError(name)
         from . import tower_hip
         self._tower = tower_hip.HipTower(self.tower, self.board_size, self.width, max_batch, self.device,
-                                         stem=self.stem, vconv=self.vconv, pconv=self.pconv)
-        return self.eval_hip
+                                         stem=self.stem, vconv=self.vconv, pconv=self.pconv,
+                                         dense=(self.vfc1[0], self.vfc1[1], self.vfc2[0], self.vfc2[1], self.pfc[0], self.pfc[1]))
+        return _HipEvaluator(self)
 
     @torch.no_grad()
     def eval_hip(self, x):
-        """af_tower_stem -> af_tower_forward -> af_tower_heads (the 1x1 convs), then the three small dense layers and
-        the softmax on PyTorch ops (0.3 MMAC per position of 604)."""
+        """The whole forward on hand-written kernels: af_tower_stem -> af_tower_forward -> af_tower_heads (the 1x1 convs)
+        -> af_tower_dense (the three dense layers + softmax on the MFMA)."""
+        B, tw = x.shape[0], self._tower
+        tw.stem(x.contiguous())
+        tw.forward(B)
+        tw.heads(B)
+        return tw.dense(B)
+
+    @torch.no_grad()
+    def eval_hip_torch_dense(self, x):
+        """A/B reference for af_tower_dense: the same pipeline with the dense layers on PyTorch ops."""
         B, tw = x.shape[0], self._tower
         tw.stem(x.contiguous())
         tw.forward(B)

@@ -109,6 +109,7 @@ class Player(object):
         self._policy = torch.zeros((1, self._C), dtype=torch.float32, device=self._dev)
         self._value = torch.zeros((1,), dtype=torch.float32, device=self._dev)
         self._reset_pending = False
+        self._adopt = None
         owner = getattr(pv_fn, "__self__", None)
         self._pv_device = getattr(owner, "eval_device", None) if pv_fn is not None else None
         self.last_visits = None
@@ -119,14 +120,39 @@ class Player(object):
 
     # -- player.py:48-51
     def reset(self, search_tree=None):
-        if search_tree is not None and len(search_tree):
-            raise NotImplementedError("adopting a foreign search tree is not supported by the device store")
         self._reset_pending = True
+        self._adopt = None
+        if search_tree is not None and len(search_tree):
+            self._adopt = self._tree_to_dump(search_tree)       # uploaded by the next get_action, after the reset
         self.root_state = None
         self.tau = self.config.init_temp
 
+    def _tree_to_dump(self, tree):
+        """A mapping state string -> State-like (.a: {(i,j): edge with n, w, p}, .sum_n) — the reference's
+        defaultdict(State) or a TreeView of this class — in the engine's tree_dump format."""
+        S, Cc = self._S, self._C
+        K = self._engine.KW2
+        states = list(tree)
+        keys = np.zeros((len(states), K), np.uint64)
+        sum_n = np.zeros(len(states), np.int32)
+        n = np.zeros((len(states), Cc), np.int32)
+        w = np.zeros((len(states), Cc), np.float32)
+        p = np.zeros((len(states), Cc), np.float32)
+        f32 = np.zeros((len(states), Cc), np.uint8)
+        for i, st in enumerate(states):
+            node = tree[st]
+            keys[i] = _eng.state_to_key(st, S)
+            sum_n[i] = int(node.sum_n)
+            for (a, b), e in node.a.items():
+                c = a * S + b
+                n[i, c], w[i, c], p[i, c] = int(e.n), float(e.w), float(e.p)
+                f32[i, c] = isinstance(e.w, np.floating) and not isinstance(e.w, np.float64)   # np.float32 running sum (SURVEY rule 2)
+        return dict(keys=keys, sum_n=sum_n, n=n, w=w, p=p, f32=f32)
+
     @property
     def tree(self):
+        if self._reset_pending and self._adopt is not None:
+            return TreeView(self._adopt, self._S)
         if self._reset_pending:
             return TreeView(dict(keys=np.zeros((0, self._engine.KW2), np.uint64), sum_n=np.zeros(0, np.int32),
                                  n=None, w=None, p=None, f32=None), self._S)
@@ -160,6 +186,9 @@ class Player(object):
         self._engine.set_training(self.training)
         self._engine.set_root(0, key, last_cell, random_a, reset_tree=self._reset_pending)
         self._reset_pending = False
+        if getattr(self, "_adopt", None) is not None:          # reset(search_tree): the adopted tree replaces the fresh store
+            self._engine.load_tree(0, self._adopt)
+            self._adopt = None
         stream = self._torch.cuda.current_stream(self._dev).cuda_stream
         # device evaluator (pv_fn is a ResNet.eval bound method): nothing has to cross the host boundary per leaf, so
         # ticks and evaluations are queued 16 at a time and the status word is read once per batch (a game whose move

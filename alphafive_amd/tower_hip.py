@@ -30,6 +30,8 @@ def lib():
         L.af_tower_set_heads.argtypes = [vp, fp, fp, fp, fp]
         L.af_tower_stem.argtypes = [vp, vp, vp, vp, C.c_int32]
         L.af_tower_heads.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
+        L.af_tower_set_dense.argtypes = [vp, fp, fp, fp, fp, fp, fp]
+        L.af_tower_dense.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32]
         L.af_tower_pix.argtypes = [vp]
         L.af_tower_plane_elems.argtypes = [vp]
         L.af_tower_plane_elems.restype = C.c_int64
@@ -55,7 +57,7 @@ def tune(key, value):
 class HipTower(object):
     """blocks = list of dicts with torch tensors res/c1/c2 = (weight OIHW, bias), as DeepResNet.tower holds them."""
 
-    def __init__(self, blocks, board_size, width, max_batch, device, stem=None, vconv=None, pconv=None):
+    def __init__(self, blocks, board_size, width, max_batch, device, stem=None, vconv=None, pconv=None, dense=None):
         self.S, self.width, self.max_batch, self.device = board_size, width, max_batch, torch.device(device)
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -74,6 +76,12 @@ class HipTower(object):
         if vconv is not None:
             keep = [host(t) for t in (vconv[0], vconv[1], pconv[0], pconv[1])]
             _check(lib().af_tower_set_heads(self._h, *[p for _, p in keep]), "af_tower_set_heads")
+        self.has_dense = dense is not None
+        if dense is not None:                          # (vfc1_w [4C][64], vfc1_b, vfc2_w [64][1], vfc2_b, pfc_w [16C][C], pfc_b)
+            keep = [host(t) for t in dense]
+            _check(lib().af_tower_set_dense(self._h, *[p for _, p in keep]), "af_tower_set_dense")
+        self.policy = torch.empty((max_batch, board_size ** 2), dtype=torch.float32, device=self.device)
+        self.value = torch.empty((max_batch,), dtype=torch.float32, device=self.device)
         self.vin = torch.empty((max_batch, 4 * board_size ** 2), dtype=torch.bfloat16, device=self.device)
         self.pin = torch.empty((max_batch, 16 * board_size ** 2), dtype=torch.bfloat16, device=self.device)
         self.pix = int(lib().af_tower_pix(self._h))
@@ -105,6 +113,18 @@ class HipTower(object):
         _check(lib().af_tower_heads(self._h, stream, self.x.data_ptr(), self.vin.data_ptr(), self.pin.data_ptr(), B),
                "af_tower_heads")
         return self.vin[:B], self.pin[:B]
+
+    def dense(self, B):
+        """vin / pin of heads() -> (policy fp32 [B, S*S] softmax, value fp32 [B]) on the MFMA dense kernel."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().af_tower_dense(self._h, stream, self.vin.data_ptr(), self.pin.data_ptr(), self.policy.data_ptr(),
+                                    self.value.data_ptr(), B), "af_tower_dense")
+        return self.policy[:B], self.value[:B]
+
+    def bind_outputs(self, policy, value):
+        """Write results straight into caller-owned device tensors (the engine's: no copy on the tick path)."""
+        assert policy.is_contiguous() and value.is_contiguous() and policy.dtype == torch.float32
+        self.policy, self.value = policy, value
 
     def forward(self, B):
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -362,8 +362,8 @@ def main():
         if deep is not None:
             roof = ({"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
                      "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"} if args.net.endswith("torch") else
-                    {"backend": "hip (af_tower_bf16.hip: bf16 MFMA stem + implicit-GEMM tower, weight-stationary, LDS-DMA staging + heads 1x1 convs; dense layers on torch)",
-                     "kernel": "deep net forward = af_tower_stem + 16x af_tower_conv + af_tower_heads + 3 dense layers (whole forward timed; af_tower_conv carries 99 % of the FLOPs)"})
+                    {"backend": "hip (af_tower_bf16.hip: bf16 MFMA stem + implicit-GEMM tower, weight-stationary, LDS-DMA staging + heads 1x1 convs + MFMA dense layers / softmax)",
+                     "kernel": "deep net forward = af_tower_stem + 16x af_tower_conv + af_tower_heads + af_tower_dense (whole forward timed; af_tower_conv carries 99 % of the FLOPs)"})
         copy_gbs = copy_bandwidth_gbs(dev)
         out = {
             "metric": "self-play moves/sec (%dx%d, %d sims/move)" % (cfg.board_size, cfg.board_size, args.sims),

@@ -156,6 +156,12 @@ int af_engine_progress(af_engine* e, void* stream, uint64_t* out);
 int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys, int32_t* sum_n, int32_t* n,
                         float* w, float* p, uint8_t* f32);
 
+/* Player.reset(search_tree) (player.py:48-51), EXTERNAL mode: replace game `game`'s store by `count` nodes in
+ * af_engine_tree_dump's format (keys [count][2KW], sum_n [count], n / w / p [count][C] by cell, f32 [count][C]).
+ * Follow with af_engine_set_root(..., reset_tree = 0). */
+int af_engine_load_tree(af_engine* e, int32_t game, int32_t count, const uint64_t* keys, const int32_t* sum_n,
+                        const int32_t* n, const float* w, const float* p, const uint8_t* f32);
+
 /* state-string codec (utils.py:156-196) <-> position key */
 int af_state_to_key(const char* state, int32_t board_size, uint64_t* key);
 int af_key_to_state(const uint64_t* key, int32_t board_size, char* out, int32_t cap);

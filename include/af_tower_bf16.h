@@ -57,6 +57,15 @@ int af_tower_stem(af_tower* t, void* stream, const float* planes_dev, void* x_de
  * vin_dev bf16 [batch][4*S*S], pin_dev bf16 [batch][16*S*S]. */
 int af_tower_heads(af_tower* t, void* stream, const void* x_dev, void* vin_dev, void* pin_dev, int32_t batch);
 
+/* The three dense layers + softmax behind the heads' 1x1 convolutions (network.py:73-76,85-88) on the same MFMA:
+ * vfc1 [4*S*S][64] + [64] (ELU), vfc2 [64][1] + [1] (tanh(x/2)), pfc [16*S*S][S*S] + [S*S] (softmax); host fp32 [in][out],
+ * rounded to bf16 when packed.  af_tower_dense: vin / pin (af_tower_heads' outputs) -> policy float32[batch][S*S],
+ * value float32[batch] — what the engine's tick consumes. */
+int af_tower_set_dense(af_tower* t, const float* vfc1_w, const float* vfc1_b, const float* vfc2_w, const float* vfc2_b,
+                       const float* pfc_w, const float* pfc_b);
+int af_tower_dense(af_tower* t, void* stream, const void* vin_dev, const void* pin_dev, float* policy_dev, float* value_dev,
+                   int32_t batch);
+
 /* A/B knobs (process-global): key 0 = B-fragment ring depth (0 = per-kernel default, 8, 12, 16), key 1 = persistent
  * workgroups (0 = one per CU), key 2 = profiling ablation bits (results wrong by design: 1 no re-staging, 2 no stores,
  * 8 no LDS reads), key 3 = convolution kernel (0 af_tower_conv = default, 1 af_tower_conv2: the slab-ring structure of

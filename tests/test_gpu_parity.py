@@ -302,3 +302,44 @@ def test_engine_rejects_bad_configuration_and_roots():
         e.set_root(0, both)
     e.set_root(0, key)
     e.close()
+
+
+def test_player_reset_adopts_a_search_tree():
+    """Player.reset(search_tree) (player.py:48-51): the handed-over tree becomes the store — round trip through the
+    engine, and get_action then honours the adopted visit counts (num = min(sims, upper - sum_n), player.py:140-143)."""
+    from alphafive_amd.player import Player
+    from alphafive_amd import utils
+    cfg = make_cfg(board_size=6, goal=4, simulation_per_step=60, upper_simulation_per_step=100)
+    pv = lambda x: pseudonet.pseudonet_np(x, 321, 8192)
+    a = Player(cfg, training=False, pv_fn=pv, seed=1, game_id=0)
+    state, last = a.get_init_state(), None
+    for _ in range(2):
+        _, act = a.get_action(state, last_action=last)
+        board = utils.step(utils.state_to_board(state, 6), act)
+        state, last = utils.board_to_state(board), act
+    tree = a.tree                                    # snapshot (TreeView: state string -> State-like)
+    d0 = a._engine.tree_dump(0)
+    b = Player(cfg, training=False, pv_fn=pv, seed=2, game_id=5)
+    b.reset(tree)
+    assert len(b.tree) == len(tree)
+    root_n = tree[state].sum_n if state in tree else 0
+    _, act_b = b.get_action(state, last_action=last)
+    d1 = b._engine.tree_dump(0)
+    k0 = {d0["keys"][i].tobytes(): i for i in range(len(d0["sum_n"]))}
+    hits = 0
+    for i in range(len(d1["sum_n"])):                # every adopted node is there, counts only grew, priors untouched
+        j = k0.get(d1["keys"][i].tobytes())
+        if j is None:
+            continue
+        hits += 1
+        assert (d1["n"][i] >= d0["n"][j]).all() and (d1["p"][i].view(np.uint32) == d0["p"][j].view(np.uint32)).all()
+        assert (d1["f32"][i] >= d0["f32"][j]).all()
+    assert hits == len(d0["sum_n"])
+    kroot = {d1["keys"][i].tobytes(): i for i in range(len(d1["sum_n"]))}
+    from alphafive_amd import engine as eng
+    ri = kroot[eng.state_to_key(state, 6).tobytes()]
+    assert d1["sum_n"][ri] == root_n + min(60, 100 - root_n)
+    _, act_a = a.get_action(state, last_action=last)  # the original player, same position, eval mode: same move
+    assert act_a == act_b
+    a.close()
+    b.close()

@@ -175,6 +175,19 @@ def test_deep_bf16_tower_kernel_matches_fp32_reference(blocks):
     p_ref = F.elu(F.conv2d(h, net.pconv[0].float(), net.pconv[1].float())).reshape(B, -1)
     assert (vin.float() - v_ref).abs().max().item() <= 2.0 ** -8 * v_ref.abs().max().item() + 1e-6
     assert (pin.float() - p_ref).abs().max().item() <= 2.0 ** -8 * p_ref.abs().max().item() + 1e-6
+    # the MFMA dense kernel (fc1+ELU, fc2+tanh(x/2), policy fc + softmax) vs the same layers on PyTorch ops: bf16 inputs and
+    # weights on both sides; the kernel keeps fp32 between the layers where the torch path rounds to bf16
+    net.vfc1 = (net.vfc1[0], (torch.randn(64, generator=g) * 0.1).to("cuda", torch.bfloat16))
+    net.pfc = (net.pfc[0], (torch.randn(121, generator=g) * 0.1).to("cuda", torch.bfloat16))
+    pv = net.select_backend("hip", B)
+    pd, vd = (t.clone() for t in pv(x))
+    pt, vt = net.eval_hip_torch_dense(x)
+    assert pd.shape == (B, 121) and (pd.sum(1) - 1).abs().max().item() < 1e-5
+    assert (pd - pt).abs().max().item() < 2e-3 and (vd - vt).abs().max().item() < 2e-2
+    assert pd.argmax(1).eq(pt.argmax(1)).float().mean().item() > 0.98
+    for Bs in (1, 31, 33):                                       # ragged tails of the 32-position workgroups
+        ps, vs = pv(x[:Bs].contiguous())
+        assert torch.equal(ps, pd[:Bs]) and torch.equal(vs, vd[:Bs])
     p, v = pv(x)                                                 # end to end through the evaluator seam
     p2, v2 = net.eval_device(x)
     assert p.shape == (B, 121) and torch.allclose(p.sum(1), torch.ones(B, device="cuda"), atol=1e-3)
