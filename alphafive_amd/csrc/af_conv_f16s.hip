@@ -486,6 +486,76 @@ __global__ __launch_bounds__(256) void af_stem_f16s(const float* __restrict__ pl
     }
 }
 
+// The same stem on the matrix cores (default): K = 3 planes x 5 rows x (5 taps padded to 8) = 15 groups of 8 = 8 k-steps; a B
+// fragment (pixel n, group (cin, ky)) is the 8-wide input window starting at column x-2 of row y+ky-2, pre-expanded into
+// LDS once per position as 3 x 15 x 11 entries of 8 fp16 ("im2row"): one aligned ds_read_b128.  The planes are 0/1 —
+// exact in fp16 — so only the weights are split: two MFMAs per k-step.  One wave = one pixel tile x the 32 couts.
+__global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict__ planes, const uint4* __restrict__ w /*[8][hi|lo][64]*/,
+                                                         const float* __restrict__ bias, float inv_scale, char* __restrict__ out, int batch) {
+    __shared__ __attribute__((aligned(16))) uint4 ent[3 * 15 * kS + 1];     // entry (cin, yy, x) = window x-2..x+5 of row yy-2
+    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    h8 W[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        const uint4 v = w[f * 64 + lane];
+        __builtin_memcpy(&W[f], &v, 16);
+    }
+    float bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bs[r] = bias[16 * kg + r];
+    const int n = 32 * wv + nn;
+    const bool ok = n < kNPIX;
+    const int nc = ok ? n : 0;
+    for (int pos = blockIdx.x; pos < batch; pos += gridDim.x) {
+        const float* pl = planes + (size_t)pos * 3 * kNPIX;
+        __syncthreads();                                                     // the previous position's reads are done
+        for (int en = threadIdx.x; en < 3 * 15 * kS; en += 256) {
+            const int cin = en / (15 * kS), rem = en - cin * 15 * kS, yy = rem / kS, x = rem - yy * kS;
+            const int y = yy - 2;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (y >= 0 && y < kS) {
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    const int xx = x - 2 + e;
+                    if (xx >= 0 && xx < kS) v[e] = (_Float16)pl[cin * kNPIX + y * kS + xx];
+                }
+            }
+            __builtin_memcpy(&ent[en], &v, 16);
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            // group g = 2 s_ + kg -> (cin, ky); g = 15 is the zero pad of K (its weights are zero: any entry will do)
+            const int ga = 2 * s_, gb = 2 * s_ + 1 < 15 ? 2 * s_ + 1 : 0;
+            const uint32_t offa = (uint32_t)((ga / 5) * 15 + ga % 5) * kS, offb = (uint32_t)((gb / 5) * 15 + gb % 5) * kS;
+            h8 b;
+            __builtin_memcpy(&b, &ent[(uint32_t)nc + (kg ? offb : offa)], 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * s_], b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * s_ + 1], b, acc, 0, 0, 0);
+        }
+        char* o = out + (size_t)pos * kSlabB + (uint32_t)(2 * kg) * kRowB + (uint32_t)(nc + kS) * 16u;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = elu1(acc[8 * hf + e] * inv_scale + bs[8 * hf + e]);
+                const _Float16 h = (_Float16)f;
+                hi[e] = h;
+                lo[e] = (_Float16)(f - (float)h);
+            }
+            if (ok) {
+                *reinterpret_cast<h8*>(o + hf * kRowB) = hi;
+                *reinterpret_cast<h8*>(o + hf * kRowB + kHalfB) = lo;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host ------------------------------------------------------------------
 struct LayerCfg { int cin, cout, pcin, CT, KS, PS, gy, pj; };
 // block b: conv1 = layer 2b, conv2 (+ projection) = layer 2b+1.  pcin: channels of the projection input folded into this
@@ -601,6 +671,8 @@ struct f16s_net {
     int max_batch = 0, device = 0, ncu = 256;
     std::vector<void*> allocs;
     float *stem_w = nullptr, *stem_b = nullptr;
+    uint4* stem_wm = nullptr;     // af_stem_mfma_f16s A fragments
+    float stem_inv_scale = 1.0f;
     uint4* w[10] = {};
     uint4* pw[10] = {};           // producer layers: the block's projection weights
     float* pbuf[5] = {};          // blocks with a separately produced projection: fp32, accumulator layout
@@ -620,6 +692,24 @@ int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::s
     auto get = [&](const std::string& k) -> const std::vector<float>& { return V.at(k); };
     rc = dev_upload(n->allocs, &n->stem_w, get("bone/conv1/kernel").data(), 75 * 32 * 4);
     if (!rc) rc = dev_upload(n->allocs, &n->stem_b, get("bone/conv1/bias").data(), 32 * 4);
+    if (!rc) {       // [k-step s][hi|lo][lane][8]: MFMA row m -> cout perm(m); k = 8*(lane>>5) + e of group g = 2s + (lane>>5) = cin*5 + ky, tap kx = e
+        const std::vector<float>& ks = get("bone/conv1/kernel");         // HWIO [5][5][3][32]
+        const float sc = pick_scale(ks, nullptr);
+        std::vector<_Float16> pk((size_t)8 * 2 * 64 * 8, (_Float16)0.0f);
+        for (int s_ = 0; s_ < 8; ++s_)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 5; ++e) {
+                    const int m = lane & 31, g = 2 * s_ + (lane >> 5);
+                    if (g >= 15) continue;
+                    const int co = 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3), cin = g / 5, ky = g % 5;
+                    const float v = ks[(size_t)((ky * 5 + e) * 3 + cin) * 32 + co] * sc;
+                    const _Float16 h = (_Float16)v;
+                    pk[(((size_t)s_ * 2 + 0) * 64 + lane) * 8 + e] = h;
+                    pk[(((size_t)s_ * 2 + 1) * 64 + lane) * 8 + e] = (_Float16)(v - (float)h);
+                }
+        rc = dev_upload(n->allocs, &n->stem_wm, pk.data(), pk.size() * 2);
+        n->stem_inv_scale = 1.0f / sc;
+    }
     for (int b = 0; b < 5 && !rc; ++b) {
         const std::string s = kBlockNames[b];
         const std::vector<float>&k1 = get(s + "_conv1/kernel"), &k2 = get(s + "_conv2/kernel"), &kr = get(s + "_res/kernel");
@@ -696,7 +786,11 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
 
 int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes, int batch) {
     if (!n || batch < 1 || batch > n->max_batch) return -1;
-    hipLaunchKernelGGL(af_stem_f16s, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
+    if (n->abl & 16)    // A/B: the VALU stem
+        hipLaunchKernelGGL(af_stem_f16s, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
+    else
+        hipLaunchKernelGGL(af_stem_mfma_f16s, dim3(std::min(batch, 1024)), dim3(256), 0, st, planes, n->stem_wm, n->stem_b, n->stem_inv_scale,
+                           n->f0, batch);
     int rc = launch_layer(n, st, 0, n->f0, nullptr, n->g[0], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 1, n->g[0], n->f0, n->o[0], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 2, n->o[0], nullptr, n->g[1], nullptr, batch, 0, 0);

@@ -1268,6 +1268,7 @@ static int g_phead = 1;          // 1: af_policy_head_mfma for boards up to 11x1
 static int g_branch = 1;         // 1: value branch on a side stream
 static int g_substreams = 1;     // >1: split the batch into that many sub-batches, one HIP stream each
 static int g_subbatch = 0;       // 0: batch / g_substreams
+static int g_seqsub = 1;         // >1: that many sequential sub-batches on the caller's stream (Infinity-Cache residency experiment)
 
 // forward pass of positions [b0, b0+batch) on stream st
 static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int b0, int batch, float* policy_all, float* value_all) {
@@ -1356,6 +1357,16 @@ int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, 
     if (!n->ready) return AF_NET_ERR_STATE;
     hipStream_t st = (hipStream_t)stream;
     const int ns = g_substreams;
+    if (g_seqsub > 1 && batch >= 512 * g_seqsub) {
+        // sequential sub-batches on ONE stream: the split-operand path re-uses its activation buffers for every sub-batch
+        // (positions are indexed from 0), so a sub-batch's producer -> consumer traffic can stay inside the Infinity Cache
+        const int sub = ((batch + g_seqsub - 1) / g_seqsub + 255) / 256 * 256;
+        for (int b0 = 0; b0 < batch; b0 += sub) {
+            const int rc = forward_range(n, st, planes, b0, batch - b0 < sub ? batch - b0 : sub, policy, value);
+            if (rc) return rc;
+        }
+        return AF_NET_OK;
+    }
     if (ns <= 1 || batch < 64 * ns) return forward_range(n, st, planes, 0, batch, policy, value);
     // sub-batches in flight on side streams: each chain's activations (<= 266 KB/position between two
     // layers) stay inside the 256 MB Infinity Cache, and one chain's kernel tails overlap another's bodies
@@ -1392,6 +1403,7 @@ int af_net_tune(int32_t cout_pad, int32_t shape) {
     if (cout_pad == 5) { g_phead = shape; return AF_NET_OK; }                       // 5: MFMA policy head (1/0)
     if (cout_pad == 4) { g_branch = shape; return AF_NET_OK; }                      // 4: value branch on a side stream (1/0)
     if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)
+    if (cout_pad == 8) { g_seqsub = shape < 1 ? 1 : shape; return AF_NET_OK; }        // 8: sequential sub-batches
     if (cout_pad == 7) { g_f16s_abl = shape; return AF_NET_OK; }                      // 7: ablation bits of af_conv_f16s (profiling)
     if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
     if (cout_pad == 2) { g_subbatch = shape; return AF_NET_OK; }                     // 2: sub-batch size (0 = batch/streams)
