@@ -717,19 +717,23 @@ __global__ __launch_bounds__(256) void af_stem_conv(const float* __restrict__ pl
     for (int co = 0; co < 32; ++co) o[(size_t)co * PP] = elu1(acc[co]);
 }
 
-// value head: 1x1 conv 32->4 + ELU, fc 4*HW->64 + ELU, fc 64->1, tanh(x/2)  (network.py:70-76,163)
+// value head: 1x1 conv 32->4 + ELU, fc 4*HW->64 + ELU, fc 64->1, tanh(x/2)  (network.py:70-76,163).
+// VPB positions per workgroup: the fc1 weights (4*HW x 64 floats = 124 KB at 11x11) are streamed from L2 once per
+// workgroup, not once per position (r1: one position per block = 0.5 GB of L2 reads per forward for 0.2 GMAC).
+constexpr int VPB = 8;
 __global__ __launch_bounds__(256) void af_value_head(const float* __restrict__ in /*[b][32][PP]*/, const float* __restrict__ wc /*[32][4]*/,
                                                      const float* __restrict__ bc, const float* __restrict__ w1 /*[4HW][64]*/,
                                                      const float* __restrict__ b1, const float* __restrict__ w2 /*[64]*/,
-                                                     const float* __restrict__ b2, float* __restrict__ value, int S, int WP, int PP) {
-    __shared__ float sh[4 * 256];
+                                                     const float* __restrict__ b2, float* __restrict__ value, int batch, int S, int WP, int PP) {
+    __shared__ float sh[VPB][4 * 256];
     __shared__ float swc[32 * 4];
-    __shared__ float s64[64];
-    const int b = blockIdx.x, t = threadIdx.x, HW = S * S;
+    __shared__ float s64[VPB][64];
+    const int b0 = blockIdx.x * VPB, t = threadIdx.x, HW = S * S;
     if (t < 128) swc[t] = wc[t];
     __syncthreads();
-    if (t < HW) {
-        const int y = t / S, x = t - y * S;
+    for (int it = t; it < VPB * HW; it += 256) {                     // 1x1 conv + ELU: item = (position q, pixel)
+        const int q = it / HW, px = it - q * HW, y = px / S, x = px - y * S;
+        const int b = b0 + q < batch ? b0 + q : batch - 1;
         const float* p = in + (size_t)b * 32 * PP + (y + 1) * WP + x + 1;
         float a0 = bc[0], a1 = bc[1], a2 = bc[2], a3 = bc[3];
 #pragma unroll 8
@@ -738,19 +742,27 @@ __global__ __launch_bounds__(256) void af_value_head(const float* __restrict__ i
             a0 = fmaf(xv, swc[c * 4 + 0], a0); a1 = fmaf(xv, swc[c * 4 + 1], a1);
             a2 = fmaf(xv, swc[c * 4 + 2], a2); a3 = fmaf(xv, swc[c * 4 + 3], a3);
         }
-        sh[0 * HW + t] = elu1(a0); sh[1 * HW + t] = elu1(a1); sh[2 * HW + t] = elu1(a2); sh[3 * HW + t] = elu1(a3);
+        sh[q][0 * HW + px] = elu1(a0); sh[q][1 * HW + px] = elu1(a1); sh[q][2 * HW + px] = elu1(a2); sh[q][3 * HW + px] = elu1(a3);
     }
     __syncthreads();
-    if (t < 64) {
-        float acc = b1[t];
-        for (int k = 0; k < 4 * HW; ++k) acc = fmaf(sh[k], w1[(size_t)k * 64 + t], acc);
-        s64[t] = elu1(acc) * w2[t];
+    {                                                                // fc1: thread = (output o, pair of positions pg)
+        const int o = t & 63, pg = t >> 6;
+        float acc0 = b1[o], acc1 = acc0;
+        const float* x0 = sh[2 * pg];
+        const float* x1 = sh[2 * pg + 1];
+        for (int k = 0; k < 4 * HW; ++k) {                           // same k order as one-position-per-block: same bits
+            const float w = w1[(size_t)k * 64 + o];
+            acc0 = fmaf(x0[k], w, acc0);
+            acc1 = fmaf(x1[k], w, acc1);
+        }
+        s64[2 * pg][o] = elu1(acc0) * w2[o];
+        s64[2 * pg + 1][o] = elu1(acc1) * w2[o];
     }
     __syncthreads();
-    if (t == 0) {
+    if (t < VPB && b0 + t < batch) {
         float s = b2[0];
-        for (int j = 0; j < 64; ++j) s += s64[j];
-        value[b] = tanhf(s * 0.5f);
+        for (int j = 0; j < 64; ++j) s += s64[t][j];
+        value[b0 + t] = tanhf(s * 0.5f);
     }
 }
 
@@ -1326,8 +1338,8 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
             launch_conv(st, a);
         }
         if (i == 2) {
-            hipLaunchKernelGGL(af_value_head, dim3(batch), dim3(256), 0, st, o[2], n->vc_w, n->vc_b, n->v1_w, n->v1_b,
-                               n->v2_w, n->v2_b, value, S, WP, PP);
+            hipLaunchKernelGGL(af_value_head, dim3((batch + VPB - 1) / VPB), dim3(256), 0, st, o[2], n->vc_w, n->vc_b, n->v1_w, n->v1_b,
+                               n->v2_w, n->v2_b, value, batch, S, WP, PP);
             if (vs != st_main) NET_HIP_OK(hipEventRecord(n->ev_value, vs));
         }
     }
