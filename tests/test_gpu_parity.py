@@ -343,3 +343,39 @@ def test_player_reset_adopts_a_search_tree():
     assert act_a == act_b
     a.close()
     b.close()
+
+
+def test_pack_kernels_across_scan_chunks_with_caps():
+    """af_engine_pack_episodes over more games than one 1024-thread scan chunk, with caps that cut inside the second and
+    third chunk: successive packs must return every finished episode exactly once, in (game, sequence) order, with the
+    ply cap respected, and identical to what one uncapped pop returns from a twin engine."""
+    from alphafive_amd.engine import SelfPlayEngine
+    S, G = 5, 2500
+    cfg = make_cfg(board_size=S, goal=4, simulation_per_step=8, upper_simulation_per_step=12)
+    mk = lambda: SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, 99, 4096), device=0, seed=17)
+    a, b = mk(), mk()
+    for sp in (a, b):
+        sp.run_ticks(260)                          # long enough for most games to finish one or two episodes (then they wait)
+        sp.check()
+    ref = b.pop_raw(cap=2 * G)                     # everything at once
+    assert len(ref) > G and [(r["game"], r["seq"]) for r in ref] == sorted((r["game"], r["seq"]) for r in ref)
+    got = []
+    for cap in (700, 1, 1300, 64, 2 * G, 5):       # odd caps: cuts land in different scan chunks
+        got += a.pop_raw(cap=cap)
+    assert len(got) == len(ref)
+    for x, y in zip(got, ref):
+        assert (x["game"], x["seq"], x["T"], x["final_value"]) == (y["game"], y["seq"], y["T"], y["final_value"])
+        assert (x["keys"] == y["keys"]).all() and (x["visits"] == y["visits"]).all() and (x["actions"] == y["actions"]).all()
+        assert (x["policies"].view(np.uint32) == y["policies"].view(np.uint32)).all() and (x["lasts"] == y["lasts"]).all()
+    # ply cap: a buffer that holds fewer plies than are pending returns a prefix and leaves the rest
+    a.run_ticks(200)
+    b.run_ticks(200)
+    box = a._outbox(4000)
+    box["max_plies"] = 50                          # (the buffer is larger than that: only the cap changes)
+    part = a.pop_raw(cap=4000)
+    assert 0 < sum(r["T"] for r in part) <= 50
+    rest = a.pop_raw(cap=2 * G + 1)
+    ref2 = b.pop_raw(cap=2 * G)
+    assert [(r["game"], r["seq"]) for r in part + rest] == [(r["game"], r["seq"]) for r in ref2]
+    a.close()
+    b.close()
