@@ -47,7 +47,6 @@ constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;
 constexpr uint32_t kRowB = kPIX * 16u;          // one unit row: 8 channels x 144 units
 constexpr uint32_t kHalfB = 4u * kRowB;         // the hi (or lo) halves of a 32-channel slab
 constexpr uint32_t kSlabB = 2u * kHalfB;        // 18,432 bytes
-constexpr int kPieces = 16;                     // LDS-DMA wave-instructions (1 KB) per slab: units 8..135 of each of the 8 unit rows
 constexpr uint32_t kLds0 = 256u;                // slack so that unit -1 of a slot stays inside LDS
 #ifndef AF_F16S_DIST
 #define AF_F16S_DIST 3
@@ -112,11 +111,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     auto slab_src = [&](int p, int j) -> const char* {
         return j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabB : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabB;
     };
-    // piece wv + 4q of a slab, q = 0..3: every wave issues exactly 4 LDS-DMA instructions per slab, right after that
-    // slab's barrier, so that "s_waitcnt vmcnt(4 * (kDist - 1))" in front of the next barrier means "everything but the
-    // kDist - 1 slabs requested last has landed".  A piece
-    // is 64 units of one unit row: units 8..71 or 72..135 (pixels sit at units 11..131; the other units of a slot are
-    // zeroed once and never written).
+    // piece wv + 4q of a slab, q = 0..3: every wave issues exactly 4 LDS-DMA instructions (1 KB each) per slab — one per item,
+    // the rest behind the slab's last item — which is what lets the counted "s_waitcnt vmcnt" in front of each barrier say
+    // "everything but what was requested after slab t+1 has landed" (see the last-item branch below).  A piece is 64 units
+    // of one unit row: units 8..71 or 72..135 (pixels sit at units 11..131; the other units of a slot are zeroed once
+    // and never written).
     auto dma_piece = [&](const char* src, uint32_t slot_off, int q) {
         const int piece = wv + 4 * q;
         const uint32_t off = (uint32_t)(piece >> 3) * kHalfB + (uint32_t)((piece >> 1) & 3) * kRowB + (8u + 64u * (piece & 1)) * 16u;

@@ -54,7 +54,7 @@ extern "C" {
 #define AF_ERR_HIP        (-2)
 #define AF_ERR_NODE_CAP   (-3)  /* a game's transposition store is full */
 #define AF_ERR_NO_ROOT    (-4)  /* get_action on a finished position (reference: IndexError at player.py:102) */
-#define AF_ERR_EP_OVERRUN (-5)  /* finished episodes were not popped in time */
+#define AF_ERR_EP_OVERRUN (-5)  /* internal assertion: a game never overwrites an un-popped episode (it waits instead) */
 #define AF_ERR_STATE      (-6)
 
 /* config.py:2-20 — the attributes Player reads (player.py:31,32,44,77,109,111,141,143,240,261) */
