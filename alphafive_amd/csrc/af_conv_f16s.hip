@@ -66,6 +66,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
 
+#ifdef AF_F16S_TIMING
+// profiling build only (tools/probe_f16s_timing.py): cycles per phase, [layer][workgroup (x + 256 y)][wave][phase]
+// phase 0 items (MFMA + reads + DMA issue), 1 vmcnt waits, 2 slab barriers, 3 k-split exchange (7: its barrier alone), 4 epilogue,
+// 5 total, 6 positions
+__device__ unsigned long long g_f16s_cycles[10][512][4][8];
+#define AF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define AF_TACC(slot, a, b) tacc[slot] += (b) - (a)
+#else
+#define AF_T(var)
+#define AF_TACC(slot, a, b)
+#endif
+
 struct F16sArgs {
     const char* in;       // S32, NSM slabs per position
     const char* in2;      // S32, NSP slabs per position (block input for the folded 1x1 projection)
@@ -211,7 +223,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         fr[0][jj][1] = rd(smem, NSP > 0, 0, 1, c_, l_, r_);                                                      \
     }
     if (XPOS) { AF_FIRST_ITEM(0u) }
+#ifdef AF_F16S_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (; pos < A.batch; pos += gridDim.x) {
+        AF_T(tp0);
         if (!XPOS) { AF_FIRST_ITEM(cur) }
 #undef AF_FIRST_ITEM
         // XACC: the cross terms (W_hi*X_lo, W_lo*X_hi; 2^-11 of the main term) get their own accumulator, so the main
@@ -265,6 +281,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     // may still be in flight: kDist - 2 whole slabs and the pieces of slab t + kDist this slab has issued
                     // so far (one per earlier item, at most 4) — then fetch slab t+1's first fragments
                     const int issued = NI - 1 < 4 ? NI - 1 : 4;
+                    AF_T(tw0);
                     if (more) {
                         if (issued == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 2) + 4) : "memory");
                         else if (issued == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 2) + 1) : "memory");
@@ -272,7 +289,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
+                    AF_T(tw1);
                     __builtin_amdgcn_s_barrier();
+                    AF_T(tw2);
+                    AF_TACC(1, tw0, tw1);
+                    AF_TACC(2, tw1, tw2);
                     if ((XPOS || j + 1 < SPP) && t + 1 < nslabs) {
 #pragma unroll
                         for (int jj = 0; jj < NT; ++jj) {
@@ -331,6 +352,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             for (int jj = 0; jj < NT; ++jj) { fr[0][jj][0] = fr[1][jj][0]; fr[0][jj][1] = fr[1][jj][1]; }
         }
 
+        AF_T(tp1);
         if (XACC) {
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj)
@@ -366,7 +388,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             AF_EXCHANGE(acc, scr)
             if (PJ == 1) AF_EXCHANGE(pac, scp)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            AF_T(tx0);
             __builtin_amdgcn_s_barrier();
+            AF_T(tx1);
+            AF_TACC(7, tx0, tx1);
             AF_COMBINE(acc, scr)
             if (PJ == 1) AF_COMBINE(pac, scp)
         }
@@ -387,6 +412,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
         }
 
+        AF_T(tp2);
         // epilogue: scale back, bias, ELU; split into halves and store (or fp32 planes for the heads).  The weight
         // rows are packed so that a lane's 16 accumulator rows are the couts 32*ctg + 16*kg + r.
         float bs[16];
@@ -432,7 +458,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 }
             }
         }
+#ifdef AF_F16S_TIMING
+        {
+            AF_T(tp3);
+            tacc[3] += tp2 - tp1; tacc[4] += tp3 - tp2; tacc[5] += tp3 - tp0; tacc[6] += 1;
+        }
+#endif
     }
+#ifdef AF_F16S_TIMING
+    if (lane == 0) {
+        tacc[0] = tacc[5] - tacc[1] - tacc[2] - tacc[3] - tacc[4];
+        const int layer = (A.abl >> 8) & 15;
+        for (int q = 0; q < 8; ++q) g_f16s_cycles[layer][blockIdx.x + 256 * blockIdx.y][wv][q] = tacc[q];
+    }
+#endif
 }
 
 // 5x5 stem (3 -> 32, SAME) + bias + ELU (network.py:63) on the VALU (2,400 MAC per pixel), output split into S32.
@@ -766,7 +805,7 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
                         int WP, int PP) {
     F16sArgs a;
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
-    a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = n->abl;
+    a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xff) | (li << 8);
     a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
     switch (li) {
         // <NSM, NSP, CT, KS, PS, OUT32, XACC>: XACC wherever weights + 2 x accumulators + fragments fit 512 registers
@@ -831,3 +870,11 @@ int f16s_read_activation(f16s_net* n, int which, int batch, float* host) {
             }
     return C;
 }
+
+#ifdef AF_F16S_TIMING
+extern "C" int af_f16s_debug_cycles(unsigned long long* host) {
+    FS_HIP_OK(hipDeviceSynchronize());
+    FS_HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_f16s_cycles), sizeof(unsigned long long) * 10 * 512 * 4 * 8));
+    return 0;
+}
+#endif
