@@ -112,6 +112,17 @@ class Player(object):
         self._adopt = None
         owner = getattr(pv_fn, "__self__", None)
         self._pv_device = getattr(owner, "eval_device", None) if pv_fn is not None else None
+        self._graph = None
+        if self._pv_device is not None and hasattr(owner, "select_backend") and getattr(owner, "device", None) is not None \
+                and owner.device.type == "cuda":
+            # pv_fn is ResNet.eval: evaluate leaves with the hand-written kernels, results written straight into the
+            # tensors the tick kernel reads (one position per launch: this path is launch-latency bound, see _search_batch)
+            try:
+                fn = owner.select_backend("hip")
+                fn.bind_outputs(self._policy, self._value)
+                self._pv_device = fn
+            except Exception:                            # e.g. libaf_net.so not built: the torch-op evaluator is still a device path
+                pass
         self.last_visits = None
 
     # -- player.py:37-46
@@ -162,8 +173,9 @@ class Player(object):
     def _evaluate_leaf(self):
         if self._pv_device is not None:
             p, v = self._pv_device(self._planes)
-            self._policy.copy_(p.reshape(1, self._C))
-            self._value.copy_(v.reshape(1))
+            if p.data_ptr() != self._policy.data_ptr():
+                self._policy.copy_(p.reshape(1, self._C))
+                self._value.copy_(v.reshape(1))
             return
         x = self._planes.cpu().numpy()
         if self.pv_fn is not None:
@@ -176,6 +188,37 @@ class Player(object):
             policy, value = self.pipe.recv()[0]
         self._policy.copy_(self._torch.from_numpy(np.ascontiguousarray(policy, np.float32).reshape(1, self._C)))
         self._value.copy_(self._torch.from_numpy(np.asarray([value], np.float32)))
+
+    def _search_batch(self, n=16):
+        """n x (tick kernel -> leaf evaluation) without touching the host.  One game is launch-latency bound (14 dependent
+        launches per simulation), so the batch is captured once into a HIP graph and replayed; if capture is not possible
+        the same launches are issued eagerly."""
+        torch = self._torch
+        key = bool(self.training)
+        if self._graph is None or self._graph[0] != key:
+            self._graph = (key, None)
+            try:
+                cur = torch.cuda.current_stream(self._dev)
+                self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), cur.cuda_stream)
+                self._evaluate_leaf()                    # warm-up outside the capture (lazy allocations, function attributes)
+                torch.cuda.synchronize(self._dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    st = torch.cuda.current_stream(self._dev).cuda_stream
+                    for _ in range(n):
+                        self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), st)
+                        self._evaluate_leaf()
+                self._graph = (key, g)
+                return                                   # (the warm-up pair already advanced the search by one tick)
+            except Exception:
+                self._graph = (key, None)
+        if self._graph[1] is not None:
+            self._graph[1].replay()
+            return
+        stream = torch.cuda.current_stream(self._dev).cuda_stream
+        for _ in range(n):
+            self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), stream)
+            self._evaluate_leaf()
 
     # -- player.py:128-147
     def get_action(self, state, e=0.25, last_action=None, random_a=False):
@@ -194,9 +237,7 @@ class Player(object):
         # ticks and evaluations are queued 16 at a time and the status word is read once per batch (a game whose move
         # is decided ignores further ticks)
         while self._pv_device is not None:
-            for _ in range(16):
-                self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), stream)
-                self._evaluate_leaf()
+            self._search_batch()
             if int(self._engine.status(stream)[0]) == _eng.STATUS_MOVE_DONE:
                 break
         while self._pv_device is None:
