@@ -44,10 +44,9 @@ def play_matches(cfg, pv0, pv1, n_games, device=0, seed0=0, seed1=1, node_cap=0,
             if not active:
                 continue
             e = engines[p]
-            for i in active:
-                key = _eng.state_to_key(utils.board_to_state(boards[i]), S)
-                lc = -1 if last[i] is None else last[i][0] * S + last[i][1]
-                e.set_root(i, key, lc, random_a=True, reset_tree=(ply < 2))      # Player.reset() before each game
+            keys = np.stack([_eng.state_to_key(utils.board_to_state(boards[i]), S) for i in active])
+            lcs = [-1 if last[i] is None else last[i][0] * S + last[i][1] for i in active]
+            e.set_roots(active, keys, lcs, random_a=True, reset_tree=(ply < 2), stream=stream)   # Player.reset() before each game
             while True:
                 e.tick(policy[p].data_ptr(), value[p].data_ptr(), planes.data_ptr(), stream)
                 st = e.status(stream)
@@ -56,8 +55,9 @@ def play_matches(cfg, pv0, pv1, n_games, device=0, seed0=0, seed1=1, node_cap=0,
                 pr, va = pvs[p](planes)
                 policy[p].copy_(pr.reshape(G, C))
                 value[p].copy_(va.reshape(G))
-            for i in active:
-                cell, _, _, _ = e.move_result(i)
+            cells = e.move_results(active, stream=stream)[0]
+            for i, cell in zip(active, cells):
+                cell = int(cell)
                 a = (cell // S, cell % S)
                 moves[i].append(cell)
                 boards[i] = utils.step(boards[i], a)

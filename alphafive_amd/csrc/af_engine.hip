@@ -904,6 +904,43 @@ __global__ __launch_bounds__(256) void af_pack_copy(EngineParams P, int max_eps,
 }
 
 // ----------------------------------------------------------------------------------------------
+// EXTERNAL mode, many games at once (arena: choose_best_player.py:38-60): set the roots / fetch the move results of n
+// games with one upload, one launch and one download instead of a device synchronisation and ~10 tiny copies per game
+// ----------------------------------------------------------------------------------------------
+// req[i] = { game, last_cell, random_a, reset_tree }, keys[i][2KW]
+__global__ __launch_bounds__(64) void af_set_roots_kernel(EngineParams P, int n, const int32_t* __restrict__ req, const u64* __restrict__ keys, int KW2) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const int g = req[4 * i], last = req[4 * i + 1], ra = req[4 * i + 2], reset = req[4 * i + 3];
+    if (reset) {                                                 // Player.reset(): player.py:48-51
+        uint32_t* slots = P.hash + (size_t)g * (P.hash_mask + 1);
+        for (uint32_t s_ = lane; s_ <= P.hash_mask; s_ += 64) slots[s_] = 0;
+        if (lane == 0) { P.nodes[g] = 0; P.nfree[g] = 0; P.tau[g] = P.init_temp; P.episode[g] += 1; P.sel[g] = 0; P.plyctr[g] = 0; }
+    }
+    if (lane < KW2) P.root[(size_t)g * KW2 + lane] = keys[(size_t)i * KW2 + lane];
+    if (lane == 0) { P.root_last[g] = last; P.random_a[g] = ra ? 1 : 0; P.phase[g] = PH_MOVE_START; P.pending[g] = 0; P.status[g] = 0; }
+}
+
+// out[i] = { action, has_policy, status/phase error (0 ok), tau bits lo, tau bits hi }, then policy[C] and visits[C]
+__global__ __launch_bounds__(64) void af_move_results_kernel(EngineParams P, int n, const int32_t* __restrict__ games, int32_t* __restrict__ out, int CP) {
+    const int i = blockIdx.x, lane = threadIdx.x, C = P.C, R = 8 + 2 * C;
+    if (i >= n) return;
+    const int g = games[i];
+    int32_t* o = out + (size_t)i * R;
+    if (lane == 0) {
+        const int ph = P.phase[g];
+        o[0] = P.action[g]; o[1] = P.has_policy[g];
+        o[2] = ph == PH_MOVE_DONE ? 0 : (ph == PH_ERROR ? P.status[g] : AF_ERR_STATE);
+        const u64 tb = (u64)__double_as_longlong(P.tau[g]);
+        o[3] = (int32_t)(uint32_t)tb; o[4] = (int32_t)(uint32_t)(tb >> 32);
+    }
+    for (int c = lane; c < C; c += 64) {
+        o[8 + c] = __float_as_int(P.policy[(size_t)g * CP + c]);
+        o[8 + C + c] = P.visits[(size_t)g * CP + c];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
 struct af_engine {
@@ -913,6 +950,8 @@ struct af_engine {
     std::vector<void*> allocs;
     std::vector<int32_t> h_i32, h_i32b;
     int32_t* pack_dev = nullptr;      // staging buffer of af_engine_pop_episodes
+    char* stage_dev = nullptr;        // staging buffer of af_engine_set_roots / af_engine_move_results
+    size_t stage_cap = 0;
     int64_t pack_cap = 0;
     std::vector<int32_t> pack_host;
     std::vector<u64> h_ct;
@@ -1016,6 +1055,7 @@ void af_engine_destroy(af_engine* e) {
     (void)hipSetDevice(e->device);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->pack_dev) (void)hipFree(e->pack_dev);
+    if (e->stage_dev) (void)hipFree(e->stage_dev);
     delete e;
 }
 
@@ -1085,6 +1125,69 @@ int af_engine_set_root(af_engine* e, int32_t game, const uint64_t* key, int32_t 
     v = 0;
     HIP_OK(hipMemcpy(P.pending + game, &v, 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(P.status + game, &v, 4, hipMemcpyHostToDevice));
+    return AF_OK;
+}
+
+int af_engine_set_roots(af_engine* e, void* stream, int32_t n, const int32_t* games, const uint64_t* keys, const int32_t* last_cells,
+                        const int32_t* random_a, const int32_t* reset_tree) {
+    if (!e || e->P.mode != AF_MODE_EXTERNAL || n < 0 || (n > 0 && (!games || !keys || !last_cells))) return AF_ERR_ARG;
+    if (n == 0) return AF_OK;
+    EngineParams& P = e->P;
+    const int KW = e->KW, KW2 = 2 * KW;
+    std::vector<int32_t> req((size_t)4 * n);
+    for (int i = 0; i < n; ++i) {
+        if (games[i] < 0 || games[i] >= P.G || last_cells[i] < -1 || last_cells[i] >= P.C) return AF_ERR_ARG;
+        const uint64_t* k = keys + (size_t)i * KW2;
+        for (int q = 0; q < KW; ++q)
+            if (((k[q] | k[KW + q]) & ~P.boardmask[q]) || (k[q] & k[KW + q])) return AF_ERR_ARG;
+        req[4 * i] = games[i]; req[4 * i + 1] = last_cells[i]; req[4 * i + 2] = random_a ? random_a[i] : 0; req[4 * i + 3] = reset_tree ? reset_tree[i] : 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rb = (size_t)4 * n * 4, kb = (size_t)n * KW2 * 8, need = rb + kb;
+    if (e->stage_cap < need) {
+        if (e->stage_dev) (void)hipFree(e->stage_dev);
+        e->stage_dev = nullptr; e->stage_cap = 0;
+        HIP_OK(hipMalloc((void**)&e->stage_dev, need * 2));
+        e->stage_cap = need * 2;
+    }
+    HIP_OK(hipMemcpyAsync(e->stage_dev, req.data(), rb, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->stage_dev + rb, keys, kb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(af_set_roots_kernel, dim3(n), dim3(64), 0, st, P, n, (const int32_t*)e->stage_dev, (const u64*)(e->stage_dev + rb), KW2);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));             // req / keys are caller memory: the upload has to be over before we return
+    return AF_OK;
+}
+
+int af_engine_move_results(af_engine* e, void* stream, int32_t n, const int32_t* games, int32_t* action_cells, int32_t* has_policy,
+                           float* policies, int32_t* visits, double* taus) {
+    if (!e || n < 0 || (n > 0 && (!games || !action_cells))) return AF_ERR_ARG;
+    if (n == 0) return AF_OK;
+    EngineParams& P = e->P;
+    for (int i = 0; i < n; ++i) if (games[i] < 0 || games[i] >= P.G) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = P.C, R = 8 + 2 * C, CP = 64 * e->KW;
+    const size_t gb = (size_t)n * 4, ob = (size_t)n * R * 4, need = gb + ob;
+    if (e->stage_cap < need) {
+        if (e->stage_dev) (void)hipFree(e->stage_dev);
+        e->stage_dev = nullptr; e->stage_cap = 0;
+        HIP_OK(hipMalloc((void**)&e->stage_dev, need * 2));
+        e->stage_cap = need * 2;
+    }
+    HIP_OK(hipMemcpyAsync(e->stage_dev, games, gb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(af_move_results_kernel, dim3(n), dim3(64), 0, st, P, n, (const int32_t*)e->stage_dev, (int32_t*)(e->stage_dev + gb), CP);
+    HIP_OK(hipGetLastError());
+    std::vector<int32_t> out((size_t)n * R);
+    HIP_OK(hipMemcpyAsync(out.data(), e->stage_dev + gb, ob, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+        const int32_t* o = out.data() + (size_t)i * R;
+        if (o[2] != 0) return o[2];
+        action_cells[i] = o[0];
+        if (has_policy) has_policy[i] = o[1];
+        if (policies) memcpy(policies + (size_t)i * C, o + 8, (size_t)C * 4);
+        if (visits) memcpy(visits + (size_t)i * C, o + 8 + C, (size_t)C * 4);
+        if (taus) { const uint64_t tb = (uint64_t)(uint32_t)o[3] | ((uint64_t)(uint32_t)o[4] << 32); memcpy(taus + i, &tb, 8); }
+    }
     return AF_OK;
 }
 

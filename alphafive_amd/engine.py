@@ -66,6 +66,8 @@ def lib():
         L.af_engine_set_root.argtypes = [vp, C.c_int32, u64p, C.c_int32, C.c_int32, C.c_int32]
         L.af_engine_move_result.argtypes = [vp, C.c_int32, i32p, i32p, f32p, i32p, C.POINTER(C.c_double)]
         L.af_engine_set_training.argtypes = [vp, C.c_int32]
+        L.af_engine_set_roots.argtypes = [vp, vp, C.c_int32, i32p, u64p, i32p, i32p, i32p]
+        L.af_engine_move_results.argtypes = [vp, vp, C.c_int32, i32p, i32p, i32p, f32p, i32p, C.POINTER(C.c_double)]
         L.af_engine_pop_episodes.argtypes = [vp, vp, C.c_int32, i32p, f32p, u64p, f32p, i32p, i32p, i32p]
         L.af_engine_pack_ints.argtypes = [vp, C.c_int32, C.c_int32]
         L.af_engine_pack_ints.restype = C.c_int64
@@ -163,6 +165,27 @@ class Engine:
         _check(lib().af_engine_move_result(self._h, game, C.byref(a), C.byref(hp), _p(pol, C.c_float),
                                            _p(vis, C.c_int32), C.byref(tau)), "af_engine_move_result")
         return a.value, (pol if hp.value else None), vis, tau.value
+
+    def set_roots(self, games, keys, last_cells, random_a=False, reset_tree=False, stream=None):
+        """Batched set_root: games int[n], keys uint64[n][2KW], last_cells int[n] (-1 = None); random_a / reset_tree scalar or [n]."""
+        n = len(games)
+        g = np.ascontiguousarray(games, np.int32)
+        k = np.ascontiguousarray(keys, np.uint64).reshape(n, self.KW2)
+        lc = np.ascontiguousarray(last_cells, np.int32)
+        ra = np.ascontiguousarray(np.broadcast_to(np.asarray(random_a, np.int32), (n,)))
+        rt = np.ascontiguousarray(np.broadcast_to(np.asarray(reset_tree, np.int32), (n,)))
+        _check(lib().af_engine_set_roots(self._h, stream, n, _p(g, C.c_int32), _p(k, C.c_uint64), _p(lc, C.c_int32),
+                                         _p(ra, C.c_int32), _p(rt, C.c_int32)), "af_engine_set_roots")
+
+    def move_results(self, games, stream=None):
+        """Batched move_result -> (actions int32[n], has_policy int32[n], policies float32[n][C], visits int32[n][C], taus float64[n])."""
+        n = len(games)
+        g = np.ascontiguousarray(games, np.int32)
+        act, hp = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        pol, vis, tau = np.zeros((n, self.C), np.float32), np.zeros((n, self.C), np.int32), np.zeros(n, np.float64)
+        _check(lib().af_engine_move_results(self._h, stream, n, _p(g, C.c_int32), _p(act, C.c_int32), _p(hp, C.c_int32),
+                                            _p(pol, C.c_float), _p(vis, C.c_int32), _p(tau, C.c_double)), "af_engine_move_results")
+        return act, hp, pol, vis, tau
 
     def counters(self, stream=None):
         out = np.zeros(len(COUNTER_NAMES), np.uint64)

@@ -111,6 +111,14 @@ int af_engine_move_result(af_engine* e, int32_t game, int32_t* action_cell, int3
                           int32_t* visits, double* tau);
 int af_engine_set_training(af_engine* e, int32_t training);
 
+/* The same for n games at once (batched arena, choose_best_player.py:38-60): one upload + one launch / one launch + one
+ * download on `stream` instead of a device synchronisation and ~10 small copies per game.  keys [n][2KW]; random_a and
+ * reset_tree may be NULL (= 0); policies / visits [n][C], has_policy, taus may be NULL. */
+int af_engine_set_roots(af_engine* e, void* stream, int32_t n, const int32_t* games, const uint64_t* keys, const int32_t* last_cells,
+                        const int32_t* random_a, const int32_t* reset_tree);
+int af_engine_move_results(af_engine* e, void* stream, int32_t n, const int32_t* games, int32_t* action_cells, int32_t* has_policy,
+                           float* policies, int32_t* visits, double* taus);
+
 /* SELFPLAY mode, device-resident hand-off of finished episodes (main.py:94 `q.put`): two small kernels on `stream`
  * compact every finished, not yet popped episode — in (game, sequence) order, at most max_episodes episodes and
  * max_plies plies; the rest waits for the next call — into ONE int32 buffer and mark them popped.  No host

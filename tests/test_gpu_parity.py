@@ -304,6 +304,64 @@ def test_engine_rejects_bad_configuration_and_roots():
     e.close()
 
 
+def test_batched_roots_and_results_equal_the_per_game_calls():
+    """af_engine_set_roots / af_engine_move_results (one launch for n games) vs af_engine_set_root / af_engine_move_result."""
+    import torch
+    from alphafive_amd import engine as eng
+    S, G = 6, 6
+    cfg = make_cfg(board_size=S, goal=4, simulation_per_step=30, upper_simulation_per_step=40)
+    from alphafive_amd import utils
+    boards = [np.zeros((S, S), np.int8) for _ in range(3)]
+    for (r, c_) in ((1, 1), (1, 2)):
+        boards[1] = utils.step(boards[1], (r, c_))
+    for (r, c_) in ((2, 2), (3, 3), (3, 1)):
+        boards[2] = utils.step(boards[2], (r, c_))
+    games = [0, 2, 5]
+    keys = np.stack([eng.state_to_key(utils.board_to_state(b_), S) for b_ in boards])
+    lcs = [-1, 1 * S + 2, 3 * S + 1]
+    outs = []
+    for batched in (False, True):
+        e = eng.Engine(cfg, G, mode=eng.MODE_EXTERNAL, training=True, seed=9)
+        planes = torch.zeros((G, 3, S, S), device="cuda")
+        pol, val = torch.zeros((G, S * S), device="cuda"), torch.zeros((G,), device="cuda")
+        for rnd in range(2):                                 # the second round searches on the trees of the first
+            if batched:
+                e.set_roots(games, keys, lcs, random_a=[0, 1, 0], reset_tree=(rnd == 0))
+            else:
+                for g, k, lc, ra in zip(games, keys, lcs, (0, 1, 0)):
+                    e.set_root(g, k, lc, random_a=bool(ra), reset_tree=(rnd == 0))
+            while True:
+                e.tick(pol.data_ptr(), val.data_ptr(), planes.data_ptr())
+                st = e.status()
+                if all(st[g] == eng.STATUS_MOVE_DONE for g in games):
+                    break
+                pr, va = pseudonet.pseudonet_torch(planes, 7, 2048)
+                pol.copy_(pr.reshape(G, -1))
+                val.copy_(va.reshape(G))
+            if batched:
+                act, hp, po, vi, tau = e.move_results(games)
+                outs.append([(int(act[i]), int(hp[i]), po[i].copy(), vi[i].copy(), float(tau[i])) for i in range(3)])
+            else:
+                r = []
+                for g in games:
+                    cell, po, vi, tau = e.move_result(g)
+                    r.append((cell, 0 if po is None else 1, po, vi, tau))
+                outs.append(r)
+        with pytest.raises(eng.EngineError):
+            e.move_results([1])                              # game 1 never got a root: not MOVE_DONE
+        bad = keys.copy()
+        bad[1, 0] |= np.uint64(1) << np.uint64(50)
+        with pytest.raises(eng.EngineError):
+            e.set_roots(games, bad, lcs)
+        e.close()
+    for a_, b_ in zip(outs[:2], outs[2:]):
+        for x, y in zip(a_, b_):
+            assert x[0] == y[0] and x[1] == y[1] and x[4] == y[4]
+            if x[2] is not None:
+                np.testing.assert_array_equal(x[2], y[2])
+            np.testing.assert_array_equal(x[3], y[3])
+
+
 def test_player_reset_adopts_a_search_tree():
     """Player.reset(search_tree) (player.py:48-51): the handed-over tree becomes the store — round trip through the
     engine, and get_action then honours the adopted visit counts (num = min(sims, upper - sum_n), player.py:140-143)."""
