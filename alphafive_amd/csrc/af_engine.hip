@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "af_engine.h"
@@ -61,6 +62,8 @@ struct EngineParams {
     int32_t* free_idx;    // [G][cap] stack of free slots below the high-water mark `nodes`
     int32_t* edge_n;
     float *edge_w, *edge_p;
+    double* edge_w64;     // AF_MODE_VALUE_F64 (pipe path, networkAPI.py:72): W as a python float; edge_w is then unused
+    int32_t w64;
     // finished-episode double buffers
     uint32_t *ep_seq, *ep_popped;
     int32_t* ep_len;
@@ -270,7 +273,7 @@ __device__ float pairwise_sum(const float* a, int n) {   // n <= 256
 #ifndef AF_TICK_MIN_WAVES
 #define AF_TICK_MIN_WAVES 4   // 4 one-wave workgroups per SIMD = 16 games per CU in flight (measured 0.075 vs 0.088 ms per tick at 3)
 #endif
-template <int KW>
+template <int KW, bool W64>
 __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EngineParams P, const float* __restrict__ policy_in,
                                                      const float* __restrict__ value_in, float* __restrict__ planes_out) {
     constexpr int CP = 64 * KW;
@@ -311,7 +314,9 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     int32_t* const nsum = P.node_sum + (size_t)g * NCAP;
     int32_t* const fre = P.free_idx + (size_t)g * NCAP;
     int32_t* const en = P.edge_n + (size_t)g * NCAP * CP;
-    float* const ew = P.edge_w + (size_t)g * NCAP * CP;
+    constexpr bool w64 = W64;                        // fp64 W rows (pipe path) are a separate instantiation: no live range of the other kind
+    float* const ew = P.edge_w + (w64 ? (size_t)0 : (size_t)g * NCAP * CP);
+    double* const ew64 = P.edge_w64 + (w64 ? (size_t)g * NCAP * CP : (size_t)0);
     float* const ep = P.edge_p + (size_t)g * NCAP * CP;
     uint32_t* const slots = P.hash + (size_t)g * (P.hash_mask + 1);
     int32_t* const pnode = P.path_node + (size_t)g * CP;
@@ -324,8 +329,13 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             const size_t off = (size_t)pnode[d] * CP + pcell[d];
             const float vv = ((depth - d) & 1) ? -v : v;
             const int32_t raw = en[off];
-            en[off] = (raw + 1) | (is_f32 ? (int32_t)0x80000000 : 0);
-            ew[off] = ew[off] + vv;
+            if (w64) {                                      // float(v): every addend is a python float
+                en[off] = raw + 1;
+                ew64[off] = ew64[off] + (double)vv;
+            } else {
+                en[off] = (raw + 1) | (is_f32 ? (int32_t)0x80000000 : 0);
+                ew[off] = ew[off] + vv;
+            }
         }
         __syncthreads();
     };
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             for (int k = 0; k < KW; ++k) {
                 const size_t off = (size_t)idx * CP + lane + 64 * k;
                 en[off] = 0;
-                ew[off] = 0.0f;
+                if (w64) ew64[off] = 0.0; else ew[off] = 0.0f;
                 ep[off] = ((legal[k] >> lane) & 1ull) ? pk[k] / s : 0.0f;
             }
             __syncthreads();
@@ -662,7 +672,8 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             if (lane == 0) nsum[idx] = sum_n;
             const uint32_t sel_id = sel++;
             int nn[KW];
-            float ww[KW], pp[KW];
+            float pp[KW];
+            typename std::conditional<W64, double, float>::type ww[KW];
             bool ff[KW];
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 const int32_t raw = en[off];
                 nn[k] = raw & 0x7fffffff;
                 ff[k] = raw < 0;
-                ww[k] = ew[off];
+                if constexpr (W64) ww[k] = ew64[off]; else ww[k] = ew[off];
                 pp[k] = ep[off];
             }
             double dd[KW];
@@ -723,7 +734,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 const bool lg = (legal[k] >> lane) & 1ull;
                 double q64;                                                 // SURVEY §8a rule 2
                 if (nn[k] == 0) q64 = 0.0;
-                else if (ff[k]) q64 = (double)(ww[k] / (float)nn[k]);
+                else if (!W64 && ff[k]) q64 = (double)((float)ww[k] / (float)nn[k]);
                 else q64 = (double)ww[k] / (double)nn[k];
                 double t;
                 if (P.training) {                                           // rule 3
@@ -991,6 +1002,8 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     if (!cfg || !out || num_games < 1) return AF_ERR_ARG;
     const int S = cfg->board_size, C = S * S;
     if (S < 2 || C > 256 || cfg->goal < 2 || cfg->goal > S || cfg->simulation_per_step < 1) return AF_ERR_ARG;
+    const int value_f64 = (mode & AF_MODE_VALUE_F64) ? 1 : 0;
+    mode &= ~AF_MODE_VALUE_F64;
     if (mode != AF_MODE_SELFPLAY && mode != AF_MODE_EXTERNAL) return AF_ERR_ARG;
     // the noise sampler is numpy's legacy gamma for shape < 1 only (include/af_noise.h); the reference uses 0.3
     if (!(cfg->dirichlet_alpha > 0.0 && cfg->dirichlet_alpha < 1.0)) return AF_ERR_ARG;
@@ -1004,7 +1017,7 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     memset(&P, 0, sizeof(P));
     P.G = num_games; P.S = S; P.C = C; P.goal = cfg->goal;
     P.sims = cfg->simulation_per_step; P.upper = cfg->upper_simulation_per_step;
-    P.training = training ? 1 : 0; P.mode = mode; P.max_ply = C;
+    P.training = training ? 1 : 0; P.mode = mode; P.max_ply = C; P.w64 = value_f64;
     P.budget = AF_DEFAULT_TICK_BUDGET; P.budget_hard = AF_DEFAULT_TICK_BUDGET_HARD;
     if (const char* b = getenv("AF_TICK_BUDGET")) { const int v = atoi(b); if (v > 0) P.budget = v; }
     if (const char* b = getenv("AF_TICK_BUDGET_HARD")) { const int v = atoi(b); if (v > 0) P.budget_hard = v; }
@@ -1030,7 +1043,8 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     A(visits, G * CP); A(policy, G * CP); A(root, G * 2 * KW); A(leaf, G * 2 * KW); A(tau, G);
     A(episode, G); A(sel, G); A(plyctr, G); A(path_node, G * CP); A(path_cell, G * CP);
     A(hash, G * hcap); A(node_key, G * node_cap * 2 * KW); A(node_sum, G * node_cap); A(free_idx, G * node_cap);
-    A(edge_n, G * node_cap * CP); A(edge_w, G * node_cap * CP); A(edge_p, G * node_cap * CP);
+    A(edge_n, G * node_cap * CP); A(edge_p, G * node_cap * CP);
+    if (value_f64) { A(edge_w64, G * node_cap * CP); A(edge_w, 64); } else { A(edge_w, G * node_cap * CP); A(edge_w64, 8); }
     A(ep_seq, G); A(ep_popped, G); A(counters, G * CT_N); A(progress, 2); A(hist, HIST_N);
     if (mode == AF_MODE_SELFPLAY) {
         const size_t R = G * 2 * P.max_ply;
@@ -1067,8 +1081,10 @@ int32_t af_engine_max_plies(const af_engine* e) { return e->P.max_ply; }
 int af_engine_tick(af_engine* e, void* stream, const float* policy_dev, const float* value_dev, float* planes_dev) {
     if (!e || !planes_dev) return AF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (e->KW == 2) hipLaunchKernelGGL(af_tick_kernel<2>, dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev, planes_dev);
-    else hipLaunchKernelGGL(af_tick_kernel<4>, dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev, planes_dev);
+#define AF_TICK(KW_, W_) hipLaunchKernelGGL((af_tick_kernel<KW_, W_>), dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev, planes_dev)
+    if (e->KW == 2) { if (e->P.w64) AF_TICK(2, true); else AF_TICK(2, false); }
+    else { if (e->P.w64) AF_TICK(4, true); else AF_TICK(4, false); }
+#undef AF_TICK
     HIP_OK(hipGetLastError());
     return AF_OK;
 }
@@ -1331,6 +1347,11 @@ int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys,
     std::vector<uint64_t> bk((size_t)hw * KW2);
     HIP_OK(hipMemcpy(bk.data(), P.node_key + nb * KW2, (size_t)hw * KW2 * 8, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(bn.data(), P.edge_n + nb * CP, (size_t)hw * CP * 4, hipMemcpyDeviceToHost));
+    if (P.w64) {                                     // fp64 store: w is rounded here, af_engine_tree_w64 has the exact rows
+        std::vector<double> bd((size_t)hw * CP);
+        HIP_OK(hipMemcpy(bd.data(), P.edge_w64 + nb * CP, (size_t)hw * CP * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < bd.size(); ++i) bw[i] = (float)bd[i];
+    } else
     HIP_OK(hipMemcpy(bw.data(), P.edge_w + nb * CP, (size_t)hw * CP * 4, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(bp.data(), P.edge_p + nb * CP, (size_t)hw * CP * 4, hipMemcpyDeviceToHost));
     int o = 0;
@@ -1390,6 +1411,10 @@ int af_engine_load_tree(af_engine* e, int32_t game, int32_t count, const uint64_
         HIP_OK(hipMemcpy(P.node_key + nb * KW2, keys, (size_t)count * KW2 * 8, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(P.node_sum + nb, sum_n, (size_t)count * 4, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(P.edge_n + nb * CP, bn.data(), bn.size() * 4, hipMemcpyHostToDevice));
+        if (P.w64) {
+            std::vector<double> bd(bw.begin(), bw.end());
+            HIP_OK(hipMemcpy(P.edge_w64 + nb * CP, bd.data(), bd.size() * 8, hipMemcpyHostToDevice));
+        } else
         HIP_OK(hipMemcpy(P.edge_w + nb * CP, bw.data(), bw.size() * 4, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(P.edge_p + nb * CP, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
     }
@@ -1416,6 +1441,49 @@ int af_state_to_key(const char* state, int32_t S, uint64_t* key) {
             ++j;
         } else return AF_ERR_ARG;
     }
+    return AF_OK;
+}
+
+// AF_MODE_VALUE_F64: the exact W rows of the live nodes, in af_engine_tree_dump's order ([count][C] doubles)
+int af_engine_tree_w64(af_engine* e, int32_t game, int32_t cap, double* w) {
+    if (!e || game < 0 || game >= e->P.G || !e->P.w64) return AF_ERR_ARG;
+    EngineParams& P = e->P;
+    const int CP = 64 * e->KW, C = P.C;
+    HIP_OK(hipDeviceSynchronize());
+    int32_t hw;
+    HIP_OK(hipMemcpy(&hw, P.nodes + game, 4, hipMemcpyDeviceToHost));
+    const size_t nb = (size_t)game * P.node_cap;
+    std::vector<int32_t> bs((size_t)(hw > 0 ? hw : 1));
+    if (hw > 0) HIP_OK(hipMemcpy(bs.data(), P.node_sum + nb, (size_t)hw * 4, hipMemcpyDeviceToHost));
+    int live = 0;
+    for (int i = 0; i < hw; ++i) live += bs[i] >= 0;
+    if (cap < live || live == 0 || !w) return live;
+    std::vector<double> bd((size_t)hw * CP);
+    HIP_OK(hipMemcpy(bd.data(), P.edge_w64 + nb * CP, (size_t)hw * CP * 8, hipMemcpyDeviceToHost));
+    int o = 0;
+    for (int i = 0; i < hw; ++i) {
+        if (bs[i] < 0) continue;
+        for (int c = 0; c < C; ++c) w[(size_t)o * C + c] = bd[(size_t)i * CP + c];
+        ++o;
+    }
+    return live;
+}
+
+// ... and the way in: overwrite the W rows of the `count` nodes af_engine_load_tree has just stored
+int af_engine_set_tree_w64(af_engine* e, int32_t game, int32_t count, const double* w) {
+    if (!e || game < 0 || game >= e->P.G || !e->P.w64 || e->P.mode != AF_MODE_EXTERNAL || count < 0 || count > e->P.node_cap || (count > 0 && !w))
+        return AF_ERR_ARG;
+    EngineParams& P = e->P;
+    const int CP = 64 * e->KW, C = P.C;
+    HIP_OK(hipDeviceSynchronize());
+    int32_t hw;
+    HIP_OK(hipMemcpy(&hw, P.nodes + game, 4, hipMemcpyDeviceToHost));
+    if (hw != count) return AF_ERR_STATE;
+    if (count == 0) return AF_OK;
+    std::vector<double> bd((size_t)count * CP, 0.0);
+    for (int i = 0; i < count; ++i)
+        for (int c = 0; c < C; ++c) bd[(size_t)i * CP + c] = w[(size_t)i * C + c];
+    HIP_OK(hipMemcpy(P.edge_w64 + (size_t)game * P.node_cap * CP, bd.data(), bd.size() * 8, hipMemcpyHostToDevice));
     return AF_OK;
 }
 

@@ -12,6 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.environ.get("AF_HIP_LIB") or os.path.join(_PKG, "_lib", "libaf_hip.so")
 
 MODE_SELFPLAY, MODE_EXTERNAL = 0, 1
+MODE_VALUE_F64 = 0x100       # OR into mode: the reference's pipe path (networkAPI.py:72 float(v)): W, Q fp64
 STATUS_IDLE, STATUS_NEED_EVAL, STATUS_MOVE_DONE, STATUS_YIELD = 0, 1, 2, 3
 BLACK_WIN, WHITE_WIN, DRAW = 1, -1, 0          # utils.py:9-11
 
@@ -73,6 +74,8 @@ def lib():
         L.af_engine_pack_ints.restype = C.c_int64
         L.af_engine_pack_episodes.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
         L.af_engine_counters.argtypes = [vp, vp, u64p]
+        L.af_engine_tree_w64.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+        L.af_engine_set_tree_w64.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
         L.af_engine_progress.argtypes = [vp, vp, u64p]
         L.af_engine_tick_histogram.argtypes = [vp, vp, u64p, C.c_int32]
         L.af_engine_set_tick_budget.argtypes = [vp, C.c_int32]
@@ -119,9 +122,11 @@ class Engine:
     """Thin RAII wrapper over af_engine_* (one handle per GPU)."""
 
     def __init__(self, cfg, num_games, device=0, mode=MODE_SELFPLAY, training=True, seed=0, first_game_id=0,
-                 node_cap=0):
+                 node_cap=0, value_f64=False):
         self._h = C.c_void_p()
         self.cfg = AfConfig.from_cfg(cfg) if not isinstance(cfg, AfConfig) else cfg
+        self.value_f64 = bool(value_f64) or bool(mode & MODE_VALUE_F64)
+        mode = (mode & ~MODE_VALUE_F64) | (MODE_VALUE_F64 if self.value_f64 else 0)
         _check(lib().af_engine_create(C.byref(self.cfg), num_games, device, mode, int(training), seed, first_game_id,
                                       node_cap, C.byref(self._h)), "af_engine_create")
         self.G = num_games
@@ -129,7 +134,7 @@ class Engine:
         self.C = self.S * self.S
         self.KW2 = lib().af_engine_key_words(self._h)
         self.max_plies = lib().af_engine_max_plies(self._h)
-        self.mode = mode
+        self.mode = mode & ~MODE_VALUE_F64
         self.device = device
         self._status = np.zeros(num_games, np.int32)
 
@@ -220,6 +225,9 @@ class Engine:
             _check(lib().af_engine_tree_dump(self._h, game, cnt, _p(keys, C.c_uint64), _p(sum_n, C.c_int32),
                                              _p(n, C.c_int32), _p(w, C.c_float), _p(p, C.c_float), _p(f, C.c_uint8)),
                    "tree_dump")
+            if self.value_f64:                   # the exact rows: W is a python float on the pipe path
+                w = np.zeros((cnt, self.C), np.float64)
+                _check(lib().af_engine_tree_w64(self._h, game, cnt, _p(w, C.c_double)), "af_engine_tree_w64")
         return dict(keys=keys, sum_n=sum_n, n=n, w=w, p=p, f32=f)
 
     def load_tree(self, game, dump):
@@ -230,6 +238,9 @@ class Engine:
         _check(lib().af_engine_load_tree(self._h, game, cnt, _p(arr["keys"], C.c_uint64), _p(arr["sum_n"], C.c_int32),
                                          _p(arr["n"], C.c_int32), _p(arr["w"], C.c_float), _p(arr["p"], C.c_float),
                                          _p(arr["f32"], C.c_uint8)), "af_engine_load_tree")
+        if self.value_f64:
+            w64 = np.ascontiguousarray(dump["w"], np.float64)
+            _check(lib().af_engine_set_tree_w64(self._h, game, cnt, _p(w64, C.c_double)), "af_engine_set_tree_w64")
 
     def pack_ints(self, max_eps, max_plies):
         return int(_check(lib().af_engine_pack_ints(self._h, max_eps, max_plies), "af_engine_pack_ints"))
@@ -294,9 +305,12 @@ class SelfPlayEngine:
 
     pv_device: callable planes float32[G,3,S,S] (torch, on device) -> (policy[G,C], value[G])
     torch tensors on the same device — alphafive_amd.network.ResNet.eval_device, or a test stub.
+    value_f64: the arithmetic of the workers main.py actually runs (values through NetworkAPI pipes as python floats,
+    networkAPI.py:72): W / Q in fp64.  Default False = the pv_fn path (self_play.py), SURVEY's parity target.
     """
 
-    def __init__(self, cfg, num_games, pv_device, device=0, seed=0, first_game_id=0, training=True, node_cap=0):
+    def __init__(self, cfg, num_games, pv_device, device=0, seed=0, first_game_id=0, training=True, node_cap=0,
+                 value_f64=False):
         import torch
         if not torch.cuda.is_available():
             raise EngineError("SelfPlayEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -305,7 +319,7 @@ class SelfPlayEngine:
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.engine = Engine(cfg, num_games, device=device, mode=MODE_SELFPLAY, training=training, seed=seed,
-                             first_game_id=first_game_id, node_cap=node_cap)
+                             first_game_id=first_game_id, node_cap=node_cap, value_f64=value_f64)
         S = cfg.board_size
         self.G, self.S, self.C = num_games, S, S * S
         self.planes = torch.zeros((num_games, 3, S, S), dtype=torch.float32, device=self.dev)

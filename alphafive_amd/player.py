@@ -103,8 +103,10 @@ class Player(object):
         self._S = cfg.board_size
         self._C = self._S * self._S
         self._dev = torch.device("cuda", device)
+        # behind a pipe the values arrive as python floats (networkAPI.py:72 `float(v)`), which makes every W / Q of the
+        # reference's tree fp64; through pv_fn they are np.float32 and W is an fp32 running sum (SURVEY 8a rule 2)
         self._engine = _eng.Engine(cfg, 1, device=device, mode=_eng.MODE_EXTERNAL, training=training, seed=seed,
-                                   first_game_id=game_id, node_cap=node_cap)
+                                   first_game_id=game_id, node_cap=node_cap, value_f64=(pv_fn is None))
         self._planes = torch.zeros((1, 3, self._S, self._S), dtype=torch.float32, device=self._dev)
         self._policy = torch.zeros((1, self._C), dtype=torch.float32, device=self._dev)
         self._value = torch.zeros((1,), dtype=torch.float32, device=self._dev)
@@ -147,7 +149,7 @@ class Player(object):
         keys = np.zeros((len(states), K), np.uint64)
         sum_n = np.zeros(len(states), np.int32)
         n = np.zeros((len(states), Cc), np.int32)
-        w = np.zeros((len(states), Cc), np.float32)
+        w = np.zeros((len(states), Cc), np.float64 if self._engine.value_f64 else np.float32)
         p = np.zeros((len(states), Cc), np.float32)
         f32 = np.zeros((len(states), Cc), np.uint8)
         for i, st in enumerate(states):

@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipe-values", action="store_true",
+                    help="W / Q in fp64: the arithmetic of main.py's pipe-fed workers (networkAPI.py:72); default = the pv_fn path")
     ap.add_argument("--net", default="hip", choices=["hip", "torch", "deep-bf16", "deep-bf16-torch"],
                     help="hip (default): the hand-written kernels, fails without libaf_net.so; torch: PyTorch-ROCm ops "
                          "(reference only); deep-bf16 = BASELINE configs[4]: 8-block width-128 net in bf16 (use with --games 8192)")
@@ -241,7 +243,7 @@ def main():
         pv = deep.select_backend("torch" if args.net.endswith("torch") else "hip", G)   # "hip" raises without libaf_tower.so
     else:
         pv = net.select_backend(args.net)
-    sp = SelfPlayEngine(cfg, G, pv, device=local, seed=args.seed, first_game_id=rank * G)
+    sp = SelfPlayEngine(cfg, G, pv, device=local, seed=args.seed, first_game_id=rank * G, value_f64=args.pipe_values)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     ev_tick, ev_net = [], []
@@ -379,7 +381,8 @@ def main():
                        if cfg.board_size == 11 else
                        (f"BASELINE configs[3]-style: {G} concurrent {cfg.board_size}x{cfg.board_size} games per GPU, "
                         f"{args.sims} sims/move (cap {args.upper}), random-init net of the same architecture, fp32"),
-                       "games_per_gpu": G, "sims_per_move": args.sims, "net_backend": roof["backend"],
+                       "games_per_gpu": G, "sims_per_move": args.sims, "tree_value_dtype": "f64 (pipe path)" if args.pipe_values else "f32 (pv_fn path)",
+                       "net_backend": roof["backend"],
                        "step": "ticks until the batch commits G more plies", "ticks_timed_rank0": n_ticks,
                        "sims_per_ply_rank0": d["sims"] / max(1, d["plies"]),
                        "selects_per_sim": d["selects"] / max(1, d["sims"]),

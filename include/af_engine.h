@@ -34,6 +34,10 @@ extern "C" {
 /* engine modes */
 #define AF_MODE_SELFPLAY 0   /* Player.run loop on device: games restart forever (main.py:82 gen_data) */
 #define AF_MODE_EXTERNAL 1   /* Player.get_action: host sets roots, engine parks when a move is decided */
+/* OR into `mode`: leaf values arrive as python floats — the reference's pipe path (networkAPI.py:72 `float(v)`, what
+ * main.py's workers run): every edge's W is an fp64 running sum and Q = W/N in fp64 (SURVEY 8a rule 2, pipe variant).
+ * Without it W follows the pv_fn path (self_play.py): fp32 running sum + the "only terminal values so far" exception. */
+#define AF_MODE_VALUE_F64 0x100
 
 /* per-game status after af_engine_tick */
 #define AF_STATUS_IDLE      0
@@ -169,6 +173,11 @@ int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys,
  * Follow with af_engine_set_root(..., reset_tree = 0). */
 int af_engine_load_tree(af_engine* e, int32_t game, int32_t count, const uint64_t* keys, const int32_t* sum_n,
                         const int32_t* n, const float* w, const float* p, const uint8_t* f32);
+
+/* AF_MODE_VALUE_F64 engines: the exact fp64 W rows ([count][C], af_engine_tree_dump's node order; its float `w` is
+ * the rounded value there), and the way in after af_engine_load_tree. */
+int af_engine_tree_w64(af_engine* e, int32_t game, int32_t cap, double* w);
+int af_engine_set_tree_w64(af_engine* e, int32_t game, int32_t count, const double* w);
 
 /* state-string codec (utils.py:156-196) <-> position key */
 int af_state_to_key(const char* state, int32_t board_size, uint64_t* key);

@@ -61,6 +61,9 @@ def lib():
         L.afo_destroy.argtypes = [vp]
         L.afo_reset.argtypes = [vp]
         L.afo_set_training.argtypes = [vp, C.c_int]
+        L.afo_set_value_f64.argtypes = [vp, C.c_int]
+        L.afo_node_get_w64.argtypes = [vp, C.c_char_p, f64p]
+        L.afo_tree_dump_w64.argtypes = [vp, C.c_int, f64p]
         L.afo_get_action.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, f32p, C.POINTER(C.c_int), i32p]
         L.afo_run.argtypes = [vp, C.c_int, C.c_char_p, f32p, C.POINTER(C.c_int), C.POINTER(C.c_int), i32p,
                               f64p, f32p, f64p]
@@ -184,7 +187,8 @@ class OraclePlayer:
     callable float32[1,3,S,S] -> (float32[1,C], float32[1]) like the reference's pv_fn."""
 
     def __init__(self, cfg, training=True, rng_mode=RNG_PHILOX, seed=0, game_id=0, pv_fn=None,
-                 pseudo_salt=0, pseudo_peak=0):
+                 pseudo_salt=0, pseudo_peak=0, value_f64=False):
+        self.value_f64 = bool(value_f64)          # the reference's pipe path (networkAPI.py:72): w, q fp64
         self.cfg = Config.from_cfg(cfg) if not isinstance(cfg, Config) else cfg
         self.S = self.cfg.board_size
         self.C = self.S * self.S
@@ -194,6 +198,8 @@ class OraclePlayer:
                                   PV_CALLBACK if pv_fn is not None else PV_PSEUDO, self._cb, None,
                                   pseudo_salt, pseudo_peak)
         assert self.h
+        if self.value_f64:
+            lib().afo_set_value_f64(self.h, 1)
 
     def _thunk(self, planes, policy, value, user):
         x = np.ctypeslib.as_array(planes, shape=(1, 3, self.S, self.S))
@@ -265,7 +271,11 @@ class OraclePlayer:
                                 _p(p, C.c_float), _p(f, C.c_uint8))
         if rc != 1:
             return None
-        return dict(sum_n=sum_n.value, n=n, w=w, p=p, f32=f)
+        out = dict(sum_n=sum_n.value, n=n, w=w, p=p, f32=f)
+        if self.value_f64:
+            out["w64"] = np.zeros(self.C, np.float64)
+            lib().afo_node_get_w64(self.h, state.encode(), _p(out["w64"], C.c_double))
+        return out
 
     def tree_dump(self):
         cnt = self.tree_size()
@@ -277,7 +287,11 @@ class OraclePlayer:
         f = np.zeros((cnt, self.C), np.uint8)
         lib().afo_tree_dump(self.h, cnt, _p(keys, C.c_uint64), _p(sum_n, C.c_int32), _p(n, C.c_int32),
                             _p(w, C.c_float), _p(p, C.c_float), _p(f, C.c_uint8))
-        return dict(keys=keys, sum_n=sum_n, n=n, w=w, p=p, f32=f)
+        out = dict(keys=keys, sum_n=sum_n, n=n, w=w, p=p, f32=f)
+        if self.value_f64:
+            out["w64"] = np.zeros((cnt, self.C), np.float64)
+            lib().afo_tree_dump_w64(self.h, cnt, _p(out["w64"], C.c_double))
+        return out
 
     def stats(self):
         out = np.zeros(5, np.uint64)

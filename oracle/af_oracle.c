@@ -272,6 +272,7 @@ typedef struct afo_node {
     int sum_n;
     int32_t* n;      /* [C] by cell */
     float* w;        /* running sum, fp32 (rule 2) */
+    double* w64;     /* pipe path (networkAPI.py:72 float(v)): running sum of python floats */
     float* p;        /* prior */
     uint8_t* f32;    /* 1 once an fp32 (net) value has been added (rule 2 exception) */
     struct afo_node* next;
@@ -282,6 +283,7 @@ typedef struct afo_node {
 struct afo_player {
     afo_config cfg;
     int S, C, training, rng_mode;
+    int value_f64;   /* 1: leaf values are python floats (pipe path): w, q fp64 throughout (SURVEY 8a rule 2) */
     uint64_t seed; uint32_t game_id, k0, k1;
     mt_t np_rng, py_rng;
     uint32_t episode, sel_ctr, ply_ctr;
@@ -318,6 +320,7 @@ static afo_node* tree_insert(afo_player* P, const bb_t* m, const bb_t* t) {
     nd->mine = *m; nd->theirs = *t;
     nd->n = (int32_t*)calloc((size_t)P->C, sizeof(int32_t));
     nd->w = (float*)calloc((size_t)P->C, sizeof(float));
+    nd->w64 = (double*)calloc((size_t)P->C, sizeof(double));
     nd->p = (float*)calloc((size_t)P->C, sizeof(float));
     nd->f32 = (uint8_t*)calloc((size_t)P->C, 1);
     uint32_t h = bb_hash(m, t);
@@ -332,7 +335,7 @@ static afo_node* tree_insert(afo_player* P, const bb_t* m, const bb_t* t) {
 static void tree_clear(afo_player* P) {
     for (int i = 0; i < P->n_nodes; ++i) {
         afo_node* nd = P->order[i];
-        free(nd->n); free(nd->w); free(nd->p); free(nd->f32); free(nd);
+        free(nd->n); free(nd->w); free(nd->w64); free(nd->p); free(nd->f32); free(nd);
     }
     P->n_nodes = 0;
     memset(P->buckets, 0, sizeof(afo_node*) * AFO_BUCKETS);
@@ -370,6 +373,7 @@ void afo_reset(afo_player* P) {
     P->episode += 1; P->sel_ctr = 0; P->ply_ctr = 0;
 }
 void afo_set_training(afo_player* P, int training) { P->training = training; }
+void afo_set_value_f64(afo_player* P, int on) { P->value_f64 = on ? 1 : 0; }
 double afo_tau(const afo_player* P) { return P->tau; }
 
 static void run_pv(afo_player* P, const float* planes, float* policy, float* value) {
@@ -427,6 +431,7 @@ static int select_edge(afo_player* P, afo_node* nd, const int8_t* board, int is_
         const int n = nd->n[c];
         double q64;                                               /* rule 2 */
         if (n == 0) q64 = 0.0;
+        else if (P->value_f64) q64 = nd->w64[c] / (double)n;
         else if (nd->f32[c]) q64 = (double)(nd->w[c] / (float)n);
         else q64 = (double)nd->w[c] / (double)n;
         double t;
@@ -476,12 +481,13 @@ static float expand(afo_player* P, const int8_t* board, const bb_t* m, const bb_
 }
 
 /* player.py:166-184 update_tree */
-static void backup(afo_node** path_nodes, const int* path_cells, int depth, float v, int is_f32) {
+static void backup(const afo_player* P, afo_node** path_nodes, const int* path_cells, int depth, float v, int is_f32) {
     for (int d = depth - 1; d >= 0; --d) {
         v = -v;
         afo_node* nd = path_nodes[d];
         const int c = path_cells[d];
         nd->n[c] += 1;
+        if (P->value_f64) { nd->w64[c] = nd->w64[c] + (double)v; continue; }   /* w += float(v) */
         nd->w[c] = nd->w[c] + v;
         if (is_f32) nd->f32[c] = 1;
     }
@@ -496,7 +502,7 @@ static void simulate(afo_player* P, const int8_t* root_board, int last_cell) {
     for (;;) {
         double tv;
         if (afo_is_game_over(board, P->S, P->cfg.goal, &tv)) {    /* :213-217 terminal first */
-            backup(path_nodes, path_cells, depth, (float)tv, 0);
+            backup(P, path_nodes, path_cells, depth, (float)tv, 0);
             P->st_terminals++;
             return;
         }
@@ -504,7 +510,7 @@ static void simulate(afo_player* P, const int8_t* root_board, int last_cell) {
         afo_node* nd = tree_find(P, &m, &t);
         if (!nd) {                                                /* :218-222 */
             float v = expand(P, board, &m, &t, last_cell);
-            backup(path_nodes, path_cells, depth, v, 1);
+            backup(P, path_nodes, path_cells, depth, v, 1);
             return;
         }
         const int cell = select_edge(P, nd, board, depth == 0);   /* :223 */
@@ -626,6 +632,22 @@ int afo_node_get(const afo_player* P, const char* state, int* sum_n, int32_t* n,
     memcpy(n, nd->n, sizeof(int32_t) * (size_t)P->C); memcpy(w, nd->w, sizeof(float) * (size_t)P->C);
     memcpy(pr, nd->p, sizeof(float) * (size_t)P->C); memcpy(f32, nd->f32, (size_t)P->C);
     return 1;
+}
+
+int afo_node_get_w64(const afo_player* P, const char* state, double* w) {
+    int8_t board[AFO_MAXC];
+    if (afo_state_to_board(state, P->S, board)) return -1;
+    bb_t m, t; board_to_bb(board, P->C, &m, &t);
+    afo_node* nd = tree_find(P, &m, &t);
+    if (!nd) return 0;
+    memcpy(w, nd->w64, sizeof(double) * (size_t)P->C);
+    return 1;
+}
+
+int afo_tree_dump_w64(const afo_player* P, int cap, double* w) {
+    int cnt = P->n_nodes < cap ? P->n_nodes : cap;
+    for (int i = 0; i < cnt; ++i) memcpy(w + (size_t)i * P->C, P->order[i]->w64, sizeof(double) * (size_t)P->C);
+    return P->n_nodes;
 }
 
 int afo_tree_dump(const afo_player* P, int cap, uint64_t* keys, int32_t* sum_n, int32_t* n, float* w, float* pr, uint8_t* f32) {

@@ -151,11 +151,36 @@ def gen_rules(path):
     print("rules:", len(cases), "cases")
 
 
-def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, random_a=False, reset_every=None, **cfg_kw):
+class _FakeAgent:
+    """Stands where ResNet stands in networkAPI.py:64-65 (`with agent_model.graph.as_default(): agent_model.eval(data)`)."""
+
+    class _Graph:
+        def as_default(self):
+            import contextlib
+            return contextlib.nullcontext()
+
+    def __init__(self, salt, peak, vbits):
+        self.graph, self.salt, self.peak, self.vbits = self._Graph(), salt, peak, vbits
+
+    def eval(self, data):
+        return pseudonet.pseudonet_np(data, self.salt, self.peak, self.vbits)
+
+
+def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, random_a=False, reset_every=None, pipe=False,
+             vbits=16, **cfg_kw):
     cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper, **cfg_kw)
     np.random.seed(seed)
     random.seed(seed)
-    pl = Player(cfg, training=training, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak))
+    api = None
+    if pipe:
+        # the path main.py's workers run (main.py:82-94 -> networkAPI.py:43-78): the UNMODIFIED NetworkAPI thread answers
+        # over a multiprocessing Pipe with (policy row, float(v)): w and q become python floats (SURVEY 8a rule 2)
+        from genData.networkAPI import NetworkAPI
+        api = NetworkAPI(cfg, _FakeAgent(salt, peak, vbits))
+        api.start(reload=False)
+        pl = Player(cfg, training=training, pipe=api.get_pipe(reload=False))
+    else:
+        pl = Player(cfg, training=training, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak, vbits))
     state = pl.get_init_state()
     last, over, ply = None, False, 0
     C = S * S
@@ -185,9 +210,11 @@ def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, 
                random_a=np.asarray(random_a), states=np.array(states), actions=np.array(actions, np.int32),
                lasts=np.array(lasts, np.int32), visits=np.array(visits), policies=np.array(policies),
                has_policy=np.array(has_pol), taus=np.array(taus), np_next=np.asarray(np_next),
-               py_next=np.asarray(py_next), finished=np.asarray(over))
+               py_next=np.asarray(py_next), finished=np.asarray(over), pipe=np.asarray(bool(pipe)), vbits=np.asarray(vbits))
     out.update(cfg_arrays(cfg))
     out.update(dump_tree(pl, S))
+    if api is not None:
+        api.done = True
     np.savez_compressed(path, **out)
     print(os.path.basename(path), "plies", ply, "nodes", len(pl.tree), "over", over)
 
@@ -285,9 +312,22 @@ def gen_edge_cases(G):
              tau_decay_rate=0.8, init_temp=2.0)
 
 
+def gen_pipe_cases(G):
+    """The pipe path (what main.py runs): values are python floats, so every W is an fp64 running sum and Q = W/N in fp64."""
+    # (sims > 2L so that simulations beyond the forced root visits exist and the values steer the search)
+    gen_mcts(G("mcts_s6_train_pipe.npz"), 6, 4, 120, 160, True, 3, 1237, 16384, 40, pipe=True, vbits=24)
+    gen_mcts(G("mcts_s11_train_pipe.npz"), 11, 5, 300, 400, True, 9, 4321, 8192, 3, pipe=True, vbits=24)
+    gen_mcts(G("mcts_s6_eval_pipe.npz"), 6, 4, 100, 120, False, 4, 77, 16384, 40, pipe=True, vbits=24)
+    # the same 24-bit values through the pv_fn seam: fp32 running sums that DO round (the 16-bit pseudo-net never does)
+    gen_mcts(G("mcts_s6_train_v24.npz"), 6, 4, 120, 160, True, 3, 1237, 16384, 40, vbits=24)
+
+
 def main():
     if "--only-edges" in sys.argv:
         gen_edge_cases(lambda name: os.path.join(HERE, name))
+        return
+    if "--only-pipe" in sys.argv:
+        gen_pipe_cases(lambda name: os.path.join(HERE, name))
         return
     if "--only-randomstack" in sys.argv:
         gen_randomstack(os.path.join(HERE, "randomstack.npz"))
@@ -311,6 +351,7 @@ def main():
     gen_run(G("run_s6.npz"), 6, 4, 60, 80, 11, 4242, 16384, 3)
     gen_run(G("run_s7.npz"), 7, 4, 40, 60, 12, 4243, 4096, 2)
     gen_edge_cases(G)
+    gen_pipe_cases(G)
 
 
 if __name__ == "__main__":

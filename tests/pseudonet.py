@@ -8,6 +8,10 @@ representable in fp32 and bit-identical on numpy / torch-CPU / torch-GPU.
     h = salt + sum_c mine_c*mix32(c+1) + theirs_c*mix32(c+1001) + last_c*mix32(c+2001)
     m_c = mix32(h ^ mix32(c+3001));  k_c = 1 + (m_c & 1023) + (peak if (m_c>>10)&7 == 0 else 0)
     policy_c = k_c / 2^17 ;  value = ((mix32(h ^ 0x9e3779b9) & 0xffff) - 32768) / 2^16
+
+vbits (default 16, what the oracle's built-in copy has): value = ((mix32(..) & (2^vbits - 1)) - 2^(vbits-1)) / 2^vbits.
+With vbits = 24 the values use the whole fp32 mantissa, so an fp32 running sum of them rounds where an fp64 one does
+not: the pipe-path goldens (W as a python float, networkAPI.py:72) use that.
 """
 import numpy as np
 
@@ -24,7 +28,7 @@ def _mix32_np(x):
     return x
 
 
-def pseudonet_np(planes, salt=0, peak=0):
+def pseudonet_np(planes, salt=0, peak=0, vbits=16):
     x = np.asarray(planes)
     B = x.shape[0]
     C = x.shape[2] * x.shape[3]
@@ -36,7 +40,7 @@ def pseudonet_np(planes, salt=0, peak=0):
     k = 1 + (m & 0x3FF) + np.where(((m >> 10) & 7) == 0, peak, 0)
     policy = k.astype(np.float32) * np.float32(1.0 / 131072.0)
     mv = _mix32_np(h ^ 0x9E3779B9)
-    value = ((mv & 0xFFFF) - 32768).astype(np.float32) * np.float32(1.0 / 65536.0)
+    value = ((mv & ((1 << vbits) - 1)) - (1 << (vbits - 1))).astype(np.float32) * np.float32(1.0 / (1 << vbits))
     return policy, value
 
 
@@ -50,7 +54,7 @@ def _mix32_t(x):
     return x
 
 
-def pseudonet_torch(planes, salt=0, peak=0):
+def pseudonet_torch(planes, salt=0, peak=0, vbits=16):
     """planes: float32[B,3,S,S] torch tensor (any device) -> (policy[B,C], value[B]) float32."""
     import torch
     x = planes
@@ -65,5 +69,5 @@ def pseudonet_torch(planes, salt=0, peak=0):
     k = 1 + (m & 0x3FF) + torch.where(((m >> 10) & 7) == 0, torch.full_like(m, peak), torch.zeros_like(m))
     policy = k.to(torch.float32) * (1.0 / 131072.0)
     mv = _mix32_t(h ^ 0x9E3779B9)
-    value = ((mv & 0xFFFF) - 32768).to(torch.float32) * (1.0 / 65536.0)
+    value = ((mv & ((1 << vbits) - 1)) - (1 << (vbits - 1))).to(torch.float32) * (1.0 / (1 << vbits))
     return policy, value

@@ -33,7 +33,10 @@ def _compare_tree(dev_dump, orc, S, root_state=None):
         seen.add(j)
         assert dev_dump["sum_n"][i] == od["sum_n"][j]
         assert (dev_dump["n"][i] == od["n"][j]).all()
-        assert (dev_dump["w"][i].view(np.uint32) == od["w"][j].view(np.uint32)).all()
+        if "w64" in od:                           # pipe variant: W is an fp64 running sum
+            assert dev_dump["w"].dtype == np.float64 and (dev_dump["w"][i] == od["w64"][j]).all()
+        else:
+            assert (dev_dump["w"][i].view(np.uint32) == od["w"][j].view(np.uint32)).all()
         assert (dev_dump["p"][i].view(np.uint32) == od["p"][j].view(np.uint32)).all()
         assert (dev_dump["f32"][i] == od["f32"][j]).all()
     if root_state is None:
@@ -78,6 +81,90 @@ def test_player_get_action_matches_oracle(S, goal, sims, upper, training, seed, 
     tv = pl.tree
     assert len(tv) == orc.tree_size()
     pl.close()
+
+
+class _PseudoAgent:
+    """agent_model of NetworkAPI (networkAPI.py:64-65) answering with the 24-bit pseudo-net."""
+
+    class _G:
+        def as_default(self):
+            import contextlib
+            return contextlib.nullcontext()
+
+    def __init__(self, salt, peak):
+        self.graph, self.salt, self.peak = self._G(), salt, peak
+
+    def eval(self, data):
+        return pseudonet.pseudonet_np(data, self.salt, self.peak, 24)
+
+
+@pytest.mark.parametrize("S,goal,sims,upper,training,seed,salt,peak", [
+    (6, 4, 120, 160, True, 3, 1237, 16384),
+    (11, 5, 300, 400, True, 9, 4321, 8192),
+    (6, 4, 100, 120, False, 4, 77, 16384),
+])
+def test_pipe_path_keeps_w_and_q_in_fp64(S, goal, sims, upper, training, seed, salt, peak):
+    """The path main.py's workers run: Player(pipe=...) behind NetworkAPI, values as python floats (networkAPI.py:72)
+    => W, Q fp64 (SURVEY 8a rule 2, pipe variant).  Drop-in Player + NetworkAPI mirror vs the oracle's pipe variant,
+    which tests/test_oracle_golden.py pins on the reference's own Player + NetworkAPI (mcts_*_pipe.npz, same settings)."""
+    from alphafive_amd.networkAPI import NetworkAPI
+    from alphafive_amd.player import Player
+    from alphafive_amd import utils
+    cfg = make_cfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper)
+    api = NetworkAPI(cfg, _PseudoAgent(salt, peak))
+    api.start(reload=False)
+    pl = Player(cfg, training=training, pipe=api.get_pipe(reload=False), seed=seed, game_id=3)
+    orc = oracle.OraclePlayer(cfg, training=training, rng_mode=oracle.RNG_PHILOX, seed=seed, game_id=3, value_f64=True,
+                              pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak, 24))
+    state, last, over, ply = pl.get_init_state(), None, False, 0
+    while not over and ply < (3 if S >= 11 else 60):
+        pol, act = pl.get_action(state, last_action=last)
+        opol, oact, ovis = orc.get_action(state, last, False)
+        assert (pl.last_visits == ovis).all() and act == oact, f"ply {ply}"
+        if opol is not None:
+            assert (pol.view(np.uint32) == opol.view(np.uint32)).all()
+        board = utils.step(utils.state_to_board(state, S), act)
+        state = utils.board_to_state(board)
+        over, _ = utils.is_game_over(board, goal)
+        last, ply = act, ply + 1
+    dd = pl._engine.tree_dump(0)
+    _compare_tree(dd, orc, S)
+    assert (dd["w"] != dd["w"].astype(np.float32)).any()      # sums that an fp32 store would have rounded
+    tv = pl.tree                                             # the State/Action view hands out python floats, as the reference
+    e = max(tv[pl.get_init_state()].a.values(), key=lambda x: x.n)
+    assert isinstance(e.w, float) and isinstance(e.q, float)
+    # reset(search_tree) keeps the fp64 rows
+    pl.reset(search_tree=tv)
+    pl.get_action(state, last_action=last) if not over else None
+    pl.close()
+    api.close()
+
+
+def test_selfplay_engine_value_f64_matches_pipe_oracle_run():
+    """SelfPlayEngine(value_f64=True): whole training episodes (Player.run, player.py:53-82) with the pipe path's fp64 W / Q."""
+    import torch
+    from alphafive_amd.engine import SelfPlayEngine
+    cfg = make_cfg(board_size=6, goal=4, simulation_per_step=100, upper_simulation_per_step=130)
+    G = 6
+    sp = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, 31, 8192, 24), device=0, seed=12, value_f64=True)
+    eps = {}
+    for _ in range(400):
+        sp.run_ticks(64)
+        sp.check()
+        for raw in sp.pop_raw(cap=64):
+            eps.setdefault(raw["game"], raw)
+        if len(eps) == G:
+            break
+    assert len(eps) == G
+    for g in range(G):
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=12, game_id=g, value_f64=True,
+                                  pv_fn=lambda x: pseudonet.pseudonet_np(x, 31, 8192, 24))
+        orec, extra = orc.run()
+        raw = eps[g]
+        assert raw["seq"] == 0 and raw["T"] == len(orec)
+        assert (raw["actions"] == extra["actions"]).all() and (raw["visits"] == extra["visits"]).all()
+        assert raw["final_value"] == extra["final_value"]
+    sp.close()
 
 
 def test_player_run_and_reset_match_oracle():

@@ -215,30 +215,40 @@ def test_deep_bf16_evaluator_plugs_into_the_engine(backend):
     sp.close()
 
 
-def test_player_pipe_mode_through_networkapi_matches_pv_fn_mode():
-    """player.py:194-197 pipe protocol end to end: Player(pipe=net.get_pipes(cfg)) against the NetworkAPI
-    worker thread + ResNet.eval, vs the same search driven through pv_fn.  (The engine keeps the pv_fn
-    path's fp32 W/Q rule in both modes — DESIGN §4 — so the two must agree bit for bit.)"""
+def test_player_pipe_mode_through_networkapi_matches_the_pipe_oracle():
+    """player.py:194-197 pipe protocol end to end: Player(pipe=net.get_pipes(cfg)) against the NetworkAPI worker thread +
+    ResNet.eval.  Behind a pipe the values are python floats (networkAPI.py:72), so the reference's W / Q are fp64 there
+    (SURVEY 8a rule 2): the engine switches to its fp64 store and must equal the oracle's pipe variant — itself pinned on
+    the reference Player behind the reference NetworkAPI (tests/golden/*_pipe.npz) — fed by the same ResNet.eval."""
+    import oracle
     from alphafive_amd.network import ResNet
     from alphafive_amd.player import Player
     from alphafive_amd import utils
     net = ResNet(11, device="cuda")
     net.load_npz(W)
-    cfg = make_cfg(simulation_per_step=40, upper_simulation_per_step=60)
+    cfg = make_cfg(simulation_per_step=280, upper_simulation_per_step=340)     # > 2 x 121: past the forced root visits
     pipe = net.get_pipes(cfg)
     a = Player(cfg, training=True, pipe=pipe, seed=4, game_id=0)
-    b = Player(cfg, training=True, pv_fn=net.eval, seed=4, game_id=0)      # same noise stream on purpose
-    b._pv_device = None                      # force the host round trip so both go through ResNet.eval
+    assert a._engine.value_f64
+    orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=4, game_id=0, pv_fn=net.eval, value_f64=True)
     state, last = a.get_init_state(), None
-    for _ in range(3):
+    for _ in range(2):
         pa, aa = a.get_action(state, last_action=last)
-        pb, ab = b.get_action(state, last_action=last)
-        assert aa == ab and (a.last_visits == b.last_visits).all()
-        assert (pa.view(np.uint32) == pb.view(np.uint32)).all()
+        po, ao, vo = orc.get_action(state, last)
+        assert aa == ao and (a.last_visits == vo).all()
+        assert (pa.view(np.uint32) == po.view(np.uint32)).all()
         board = utils.step(utils.state_to_board(state, 11), aa)
         state, last = utils.board_to_state(board), aa
+    dd, od = a._engine.tree_dump(0), orc.tree_dump()
+    omap = {od["keys"][i][[0, 1, 4, 5]].tobytes(): i for i in range(len(od["sum_n"]))}
+    rounded = 0
+    for i in range(len(dd["sum_n"])):
+        j = omap[dd["keys"][i].tobytes()]
+        assert (dd["n"][i] == od["n"][j]).all() and not dd["f32"][i].any()
+        assert dd["w"].dtype == np.float64 and (dd["w"][i] == od["w64"][j]).all()
+        rounded += int((dd["w"][i] != dd["w"][i].astype(np.float32)).sum())
+    assert rounded > 0                       # the sums really left the fp32 grid: an fp32 store could not have matched
     a.close()
-    b.close()
     net.close()
 
 

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
+import pseudonet
 from conftest import GOLDEN, cfg_from_golden
 
 
@@ -59,8 +60,11 @@ def test_mcts_trace_bit_exact(path):
     z = dict(np.load(path))
     cfg = cfg_from_golden(z)
     S = cfg.board_size
-    pl = oracle.OraclePlayer(cfg, training=bool(z["training"]), rng_mode=oracle.RNG_MT, seed=int(z["seed"]),
-                             pseudo_salt=int(z["salt"]), pseudo_peak=int(z["peak"]))
+    pipe = bool(z.get("pipe", False))            # *_pipe.npz: the reference Player behind its NetworkAPI pipe (fp64 w / q)
+    vbits = int(z.get("vbits", 16))
+    pv = None if vbits == 16 else (lambda x: pseudonet.pseudonet_np(x, int(z["salt"]), int(z["peak"]), vbits))
+    pl = oracle.OraclePlayer(cfg, training=bool(z["training"]), rng_mode=oracle.RNG_MT, seed=int(z["seed"]), pv_fn=pv,
+                             pseudo_salt=int(z["salt"]), pseudo_peak=int(z["peak"]), value_f64=pipe)
     for t in range(len(z["states"])):
         pol, act, vis = pl.get_action(str(z["states"][t]), _cell(S, z["lasts"][t]), bool(z["random_a"]))
         assert (vis == z["visits"][t]).all(), f"ply {t}: visit counts differ"
@@ -81,6 +85,13 @@ def test_mcts_trace_bit_exact(path):
         assert nd["sum_n"] == z["tree_sum_n"][k]
         legal = z["tree_legal"][k].astype(bool)
         assert (nd["n"] == z["tree_n"][k]).all()
+        if pipe:
+            assert (nd["w64"] == z["tree_w"][k]).all() and not z["tree_wf32"][k].any()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                q = np.where(nd["n"] == 0, 0.0, nd["w64"] / nd["n"].astype(np.float64))
+            assert (q == z["tree_q"][k]).all()
+            assert (nd["p"] == z["tree_p"][k]).all()
+            continue
         assert (nd["w"].astype(np.float64) == z["tree_w"][k]).all()
         assert (nd["f32"][legal] == z["tree_wf32"][k][legal]).all()
         assert (nd["p"] == z["tree_p"][k]).all()
