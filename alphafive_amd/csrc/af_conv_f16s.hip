@@ -603,9 +603,9 @@ struct LayerCfg { int cin, cout, pcin, CT, KS, PS, gy, pj; };
 const LayerCfg kLayers[10] = {
     {32, 64, 0, 2, 1, 2, 1, 0},   {64, 64, 32, 2, 1, 2, 1, 0},      // bone/block1
     {64, 128, 0, 4, 1, 1, 1, 0},  {128, 128, 64, 2, 2, 1, 2, 0},    // bone/block2
-    {128, 32, 0, 1, 2, 2, 1, 1},  {32, 32, 0, 1, 2, 2, 1, 2},       // value/block3
+    {128, 32, 0, 1, 2, 2, 1, 1},  {32, 32, 0, 1, 1, 4, 1, 2},       // value/block3
     {128, 64, 0, 2, 2, 1, 1, 0},  {64, 64, 128, 2, 2, 1, 1, 0},     // policy/block4
-    {64, 32, 0, 1, 2, 2, 1, 1},   {32, 32, 0, 1, 2, 2, 1, 2},       // policy/block5
+    {64, 32, 0, 1, 1, 4, 1, 1},   {32, 32, 0, 1, 1, 4, 1, 2},       // policy/block5
 };
 const char* const kBlockNames[5] = {"bone/block1", "bone/block2", "value/block3", "policy/block4", "policy/block5"};
 
@@ -814,11 +814,11 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
         case 2: return launch_cfg<2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
         case 3: return launch_cfg<4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
         case 4: return launch_cfg<4, 0, 1, 2, 2, false, false, 1>(st, a, 1, n->ncu);   // (no XACC: weights + projection weights + 3 accumulator sets would spill)
-        case 5: return launch_cfg<1, 0, 1, 2, 2, true, true, 2>(st, a, 1, n->ncu);
+        case 5: return launch_cfg<1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);      // (one pixel tile per wave, whole K: no k-split exchange)
         case 6: return launch_cfg<4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
         case 7: return launch_cfg<2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
-        case 8: return launch_cfg<2, 0, 1, 2, 2, false, true, 1>(st, a, 1, n->ncu);
-        default: return launch_cfg<1, 0, 1, 2, 2, true, true, 2>(st, a, 1, n->ncu);
+        case 8: return launch_cfg<2, 0, 1, 1, 4, false, true, 1>(st, a, 1, n->ncu);
+        default: return launch_cfg<1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
     }
 }
 
