@@ -185,8 +185,8 @@ class Player(object):
             policy, value = policy[0], value[0]
         else:
             self.pipe.send([x[0]])
-            while not self.pipe.poll():
-                pass
+            while not self.pipe.poll(0.001):       # player.py:195-196 busy-waits on poll(); blocking in select() instead leaves
+                pass                               # the core (and, with the NetworkAPI thread in this process, the GIL) to the server
             policy, value = self.pipe.recv()[0]
         self._policy.copy_(self._torch.from_numpy(np.ascontiguousarray(policy, np.float32).reshape(1, self._C)))
         self._value.copy_(self._torch.from_numpy(np.asarray([value], np.float32)))

@@ -224,23 +224,23 @@ def test_player_pipe_mode_through_networkapi_matches_the_pipe_oracle():
     from alphafive_amd.network import ResNet
     from alphafive_amd.player import Player
     from alphafive_amd import utils
-    net = ResNet(11, device="cuda")
-    net.load_npz(W)
-    cfg = make_cfg(simulation_per_step=280, upper_simulation_per_step=340)     # > 2 x 121: past the forced root visits
+    S = 6                                    # (a 6x6 net of the same architecture, random init: every evaluation crosses the
+    net = ResNet(S, device="cuda", seed=3)   # pipe and two GIL hand-overs, so the test is sized by its evaluation count)
+    cfg = make_cfg(board_size=S, goal=4, simulation_per_step=100, upper_simulation_per_step=150)   # > 2 x 36: past the forced root visits
     pipe = net.get_pipes(cfg)
     a = Player(cfg, training=True, pipe=pipe, seed=4, game_id=0)
     assert a._engine.value_f64
     orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=4, game_id=0, pv_fn=net.eval, value_f64=True)
     state, last = a.get_init_state(), None
-    for _ in range(2):
+    for _ in range(3):
         pa, aa = a.get_action(state, last_action=last)
         po, ao, vo = orc.get_action(state, last)
         assert aa == ao and (a.last_visits == vo).all()
         assert (pa.view(np.uint32) == po.view(np.uint32)).all()
-        board = utils.step(utils.state_to_board(state, 11), aa)
+        board = utils.step(utils.state_to_board(state, S), aa)
         state, last = utils.board_to_state(board), aa
     dd, od = a._engine.tree_dump(0), orc.tree_dump()
-    omap = {od["keys"][i][[0, 1, 4, 5]].tobytes(): i for i in range(len(od["sum_n"]))}
+    omap = {od["keys"][i][[0, 1, 4, 5]].tobytes(): i for i in range(len(od["sum_n"]))}     # 2-word keys (36 cells)
     rounded = 0
     for i in range(len(dd["sum_n"])):
         j = omap[dd["keys"][i].tobytes()]
