@@ -122,17 +122,21 @@ def make_eval(resnet):
 # 3x3 + folded 1x1 convolution MACs per pixel of the five residual blocks (network.py:52-88): the part of the forward
 # pass that runs on af_conv_f16s, each MAC issued as three fp16 MFMA MACs (hi*hi, hi*lo, lo*hi)
 _SPLIT_MAC_PER_PIXEL = sum(9 * ci * co + 9 * co * co + ci * co for ci, co in ((32, 64), (64, 128), (128, 32), (128, 64), (64, 32)))
-# HBM bytes per position of that path (S32 activations, 18,432 B per 32-channel slab; weights stay in registers):
-# slabs read (3x3 input + block input of the projection; block2's conv2 reads its position from two workgroups, the
-# second read is an L2 hit) + slabs written + the two fp32 head inputs + the input planes
-_SPLIT_BYTES_PER_POSITION = (36 * 16384 + 18 * 15488 + 2 * 32 * 121 * 4 + 3 * 121 * 4)
+# HBM bytes per position of that path (S32 activations: a 32-channel slab is 16,384 B as the LDS-DMA reads it and 15,488 B
+# as the epilogue writes it (121 pixels x 8 unit rows x 16 B); weights stay in registers):
+#   slab reads   1 | 2+1 | 2 | 4+2 | 4 | 1 | 4 | 2+4 | 2 | 1 = 30  (3x3 input + block input of a folded 1x1 projection; block2's conv2
+#                reads its position from two workgroup kinds, the second read is an L2 hit)
+#   slab writes  stem 1 | 2 | 2 | 4 | 4 | 1 | - | 2 | 2 | 1 | - = 19
+#   blocks 3 and 5: the separately computed projection, fp32 in accumulator layout (16,384 B), written by conv1 and read by conv2
+#   head inputs: 32 fp32 planes of 121 pixels written by each branch's last conv and read by its head; input planes; outputs
+_SPLIT_BYTES_PER_POSITION = (30 * 16384 + 19 * 15488 + 2 * 2 * 16384 + 2 * 2 * 32 * 121 * 4 + 3 * 121 * 4 + 122 * 4)
 
 
 def roofline_info(board_size=11):
     if board_size == 11:
         return {"backend": "hip (af_conv_f16s.hip: fp16 split-operand implicit-GEMM convs on v_mfma_f32_32x32x16_f16, "
                            "fp32 accumulate, weight-stationary, LDS-DMA slab ring; stem / heads from af_net.hip)",
-                "kernel": "af_net_forward = af_stem_f16s + 10x af_conv_f16s + af_value_head + af_policy_head_mfma "
+                "kernel": "af_net_forward = af_stem_mfma_f16s + 10x af_conv_f16s + af_value_head + af_policy_head_mfma "
                           "(whole forward timed; af_conv_f16s carries 99 % of the algorithmic FLOPs, each MAC issued as "
                           "3 fp16 MFMA MACs)",
                 "peak_tflops": 2500.0, "issued_flop_per_position": 2 * 3 * _SPLIT_MAC_PER_PIXEL * 121,

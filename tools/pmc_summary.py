@@ -14,5 +14,6 @@ for k, c, v, d in rows:
 for k in acc:
     print(k[:90])
     for c, vs in sorted(acc[k].items()):
+        total = len(vs)
         vs = vs[-last:] if last else vs
-        print(f"   {c:<34} n={len(vs):<5} mean={sum(vs)/len(vs):.4g}")
+        print(f"   {c:<34} n={len(vs):<5} mean={sum(vs)/len(vs):.4g} dispatches={total}")
