@@ -17,8 +17,10 @@ void f16s_destroy(f16s_net* n);
 // stem + bone/block1 + bone/block2 on stream st
 int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes_dev, int batch);
 // value/block3 -> o3, policy/block4+5 -> o5: fp32 planes [batch][32][PP], pixel (y,x) at (y+1)*WP + x+1 (the head kernels' input)
-int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3_dev, int WP, int PP);
-int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5_dev, int WP, int PP);
+// value / policy != nullptr: the branch's last conv also applies the head's 1x1 convolution and the head's dense layers run on the
+// same split-operand MFMA (af_value_fc_f16s / af_policy_fc_f16s) -> value [batch] / policy [batch][121]; o3 / o5 are then not written
+int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3_dev, int WP, int PP, float* value);
+int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5_dev, int WP, int PP, float* policy);
 void f16s_set_ablation(f16s_net* n, int bits);
 int f16s_read_activation(f16s_net* n, int which, int batch, float* host);
 

@@ -92,11 +92,18 @@ struct F16sArgs {
     const uint4* pw;      // PJ = 1: projection A fragments [cout tile][ks][2 * NSM * C16][64]
     float* pbuf;
     float inv_scale_p;
+    // HD > 0 (fused head input): the last conv of a head branch also applies the head's 1x1 convolution (32 -> 4 value / 16 policy
+    // channels) + ELU to the tile it has just finished — the activations a lane holds ARE two MFMA B fragments — and writes
+    // the result split into halves in the layout the dense kernels read (see af_value_fc_f16s / af_policy_fc_f16s)
+    const uint4* hw;      // [k-step 2][hi|lo][64 lanes] A fragments of the 1x1 convolution, MFMA row m -> cout 8*((m>>2)&1) + 4*(m>>3) + (m&3)
+    const float* hbias;   // [16]
+    char* hx;             // value: [position][hi|lo][128 pixels][4] fp16; policy: [position][hi|lo][128 pixels][16] fp16
+    float inv_scale_h;
     int batch, WP, PP;
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
 };
 
-template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ>
+template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_conv_f16s(F16sArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 4 / PS;                    // pixel tiles per wave
@@ -172,6 +179,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             __builtin_memcpy(&PW[f], &v, 16);
         }
     }
+    h8 HA[HD > 0 ? 4 : 1];
+    float hb[HD > 0 ? 8 : 1];
+    if (HD > 0) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint4 v = A.hw[f * 64 + lane];
+            __builtin_memcpy(&HA[f], &v, 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) hb[r] = A.hbias[8 * kg + r];
+    }
     // lane geometry per pixel tile: LDS byte base of tap (0,0) in slot 0, zero-region twin, output unit
     uint32_t lb[NT], zb[NT];
     int pix[NT];
@@ -193,6 +211,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     if (PJ == 1) {
 #pragma unroll
         for (int f = 0; f < 2 * NPW; ++f) asm volatile("" : "+v"(PW[f]));
+    }
+    if (HD > 0) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(HA[f]));
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -432,7 +454,53 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 if (PJ == 2) pre += padd[jj % NFIN][r / 4][r % 4];       // (a wave's own tiles are jj / NFIN == ks)
                 v[r] = elu1(pre);
             }
-            if (OUT32) {
+            if (HD > 0) {
+                // a lane holds channels 16 kg + r of its pixel: r = 0..7 and r = 8..15 are the B fragments of two k-steps whose k
+                // index 8 kgrp + e stands for channel 16 kgrp + 8 step + e (the A fragments are packed to match)
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int st_ = 0; st_ < 2; ++st_)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = v[8 * st_ + e];
+                        const _Float16 h = (_Float16)f;
+                        bh[st_][e] = h;
+                        bl[st_][e] = (_Float16)(f - (float)h);
+                    }
+                f32x16 a2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a2[r] = 0.0f;
+#pragma unroll
+                for (int st_ = 0; st_ < 2; ++st_) {
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_], bh[st_], a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_], bl[st_], a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_ + 1], bh[st_], a2, 0, 0, 0);
+                }
+                // accumulator rows 0..7 of a lane = head channels 8 kg + r
+                constexpr int NR = HD == 1 ? 4 : 8;
+                _Float16 uh[8], ul[8];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float f = elu1(a2[r] * A.inv_scale_h + hb[r]);
+                    const _Float16 h = (_Float16)f;
+                    uh[r] = h;
+                    ul[r] = (_Float16)(f - (float)h);
+                }
+                if (ok[jj] && !(A.abl & 2)) {
+                    if (HD == 1) {
+                        if (kg == 0) {
+                            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                            char* o = A.hx + (size_t)pos * 2048u + (uint32_t)pix[jj] * 8u;
+                            *reinterpret_cast<h4*>(o) = h4{uh[0], uh[1], uh[2], uh[3]};
+                            *reinterpret_cast<h4*>(o + 1024) = h4{ul[0], ul[1], ul[2], ul[3]};
+                        }
+                    } else {
+                        char* o = A.hx + (size_t)pos * 8192u + (uint32_t)pix[jj] * 32u + (uint32_t)kg * 16u;
+                        *reinterpret_cast<h8*>(o) = h8{uh[0], uh[1], uh[2], uh[3], uh[4], uh[5], uh[6], uh[7]};
+                        *reinterpret_cast<h8*>(o + 4096) = h8{ul[0], ul[1], ul[2], ul[3], ul[4], ul[5], ul[6], ul[7]};
+                    }
+                }
+            } else if (OUT32) {
                 const int y = pix[jj] / kS, x = pix[jj] - y * kS;
                 float* o = A.out32 + ((size_t)pos * (nso * 32) + 32 * ctg + 16 * kg) * A.PP + (y + 1) * A.WP + x + 1;
                 if (ok[jj] && !(A.abl & 2)) {
@@ -594,6 +662,175 @@ __global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------------
+// The dense layers of the two heads on the same split-operand MFMA (network.py:70-76 value, :82-88 policy).  Their inputs
+// come from the fused 1x1 convolution of the branch's last conv kernel (HD above), already split into halves:
+//   value   xv [position][hi|lo][128 pixels][4 channels]   fp16 (2 KB / position)
+//   policy  xp [position][hi|lo][128 pixels][16 channels]  fp16 (8 KB / position)
+// and a k-step of 16 is chosen so that 16 contiguous bytes of a position ARE a lane's B operand: value k = 4 pixels x 4
+// channels, policy k = the 16 channels of one pixel.  The dense weights are streamed from L2 as pre-packed A fragments.
+// ----------------------------------------------------------------------------------------------------------------------------
+// value: fc1 484 -> 64 + ELU, fc2 64 -> 1, tanh(x/2).  Workgroup = 32 positions x 2 waves (cout tile mt of 32).  The whole job is
+// 93 MFMAs per wave: what matters is that a wave's operand loads are all in flight at once (two batches of 16 k-steps).
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void af_value_fc_f16s(
+    const char* __restrict__ xv, const uint4* __restrict__ a /*[31][2][hi|lo][64]*/, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, float inv_scale, float* __restrict__ value, int batch) {
+    __shared__ float red[2][32];
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, n = lane & 31, kg = lane >> 5;
+    const int pos = (int)blockIdx.x * 32 + n, posc = pos < batch ? pos : batch - 1;
+    const char* xb = xv + (size_t)posc * 2048u + (uint32_t)kg * 16u;
+    const uint4* ap = a + (size_t)mt * 128 + lane;                          // + step * 256 + half * 64
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint4 bh[16], bl[16], ah[16], al[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int s_ = 16 * half + q;
+            if (s_ < 31) {
+                bh[q] = *reinterpret_cast<const uint4*>(xb + s_ * 32);
+                bl[q] = *reinterpret_cast<const uint4*>(xb + 1024 + s_ * 32);
+                ah[q] = ap[(size_t)s_ * 256];
+                al[q] = ap[(size_t)s_ * 256 + 64];
+            }
+        }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {                          // every load above is issued before the first MFMA waits
+            if (16 * half + q < 31) {
+                u32x4 t0, t1, t2, t3;
+                __builtin_memcpy(&t0, &bh[q], 16); __builtin_memcpy(&t1, &bl[q], 16); __builtin_memcpy(&t2, &ah[q], 16); __builtin_memcpy(&t3, &al[q], 16);
+                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                __builtin_memcpy(&bh[q], &t0, 16); __builtin_memcpy(&bl[q], &t1, 16); __builtin_memcpy(&ah[q], &t2, 16); __builtin_memcpy(&al[q], &t3, 16);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (16 * half + q < 31) {
+                h8 xh, xl, wh, wl;
+                __builtin_memcpy(&xh, &bh[q], 16); __builtin_memcpy(&xl, &bl[q], 16);
+                __builtin_memcpy(&wh, &ah[q], 16); __builtin_memcpy(&wl, &al[q], 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+            }
+        }
+    }
+    float part = 0.0f;                                   // a lane's 16 accumulator rows = outputs 32 mt + 16 kg + r
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = 32 * mt + 16 * kg + r;
+        part += elu1(acc[r] * inv_scale + b1[j]) * w2[j];
+    }
+    part += __shfl_xor(part, 32);
+    if (kg == 0) red[mt][n] = part;
+    __syncthreads();
+    if (mt == 0 && kg == 0 && pos < batch) value[pos] = tanhf((red[0][n] + red[1][n] + b2[0]) * 0.5f);
+}
+
+// policy: fc 1936 -> 121, softmax.  Workgroup = 32 positions x 8 waves = (tile of 32 logits) x (half of K): two waves per SIMD, so
+// that one wave's LDS / L2 latency sits under the other's MFMAs (the compiler would not keep the operand fetch of a single wave
+// ahead of its MFMAs: 30 us; a fully unrolled, hand-prefetched single-wave variant was slower still).  The positions' inputs are
+// staged through LDS 16 pixels at a time per K half (transposed to [half][pixel][channel octet][position] rows of 528 bytes:
+// conflict-free ds_read_b128 B fragments), the A fragments ride a 16-step register ring.
+constexpr uint32_t kPfRow = 528u, kPfBuf = 64u * kPfRow;
+constexpr uint32_t kPfLds = 4u * kPfBuf;                                    // [K half][double buffer]; later the logits [32][128] floats
+__global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restrict__ xp, const uint4* __restrict__ a /*[121][4][hi|lo][64]*/,
+                                                            const float* __restrict__ bf, float inv_scale, float* __restrict__ policy, int batch) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    const int t = threadIdx.x & 255, kh = threadIdx.x >> 8, lane = t & 63, mt = t >> 6, n = lane & 31, kg = lane >> 5;
+    const int b0 = (int)blockIdx.x * 32;
+    char* const sm = psm + (uint32_t)kh * 2u * kPfBuf;
+    // K half kh = chunks 4 kh .. 4 kh + 3 of 16 pixels (the last one has 9).  Staging of a chunk: unit u = 256 i + t, i = 0..7:
+    // segment u >> 5 = (position, half), 16-byte unit u & 31 = (pixel, octet)
+    const char* src[8];
+    uint32_t dst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int u = 256 * i + t, seg = u >> 5, pl = seg >> 1, hl = seg & 1, wi = u & 31, px = wi >> 1, oc = wi & 1;
+        const int p = b0 + pl < batch ? b0 + pl : batch - 1;
+        src[i] = xp + (size_t)p * 8192u + (uint32_t)hl * 4096u + (uint32_t)(64 * kh + px) * 32u + (uint32_t)oc * 16u;
+        dst[i] = (uint32_t)((hl * 16 + px) * 2 + oc) * kPfRow + (uint32_t)pl * 16u;
+    }
+    uint4 stg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const uint4*>(src[i]);
+    uint4 ring[16][2];
+    const int step0 = 64 * kh, nstep = kh ? 57 : 64;
+    const uint4* ap = a + (size_t)step0 * 512 + (size_t)mt * 128 + lane;     // + step * 512 + half * 64
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { ring[q][0] = ap[(size_t)q * 512]; ring[q][1] = ap[(size_t)q * 512 + 64]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sm + dst[i]) = stg[i];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    __syncthreads();
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t cur = (uint32_t)(c & 1) * kPfBuf, nxt = kPfBuf - cur;
+        if (c < 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const uint4*>(src[i] + (size_t)(c + 1) * 512u);
+        }
+        const char* bb = sm + cur + (uint32_t)kg * kPfRow + (uint32_t)n * 16u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int step = 16 * c + q;
+            if (step < nstep) {
+                const h8 bh = *reinterpret_cast<const h8*>(bb + (uint32_t)(2 * q) * kPfRow);
+                const h8 bl = *reinterpret_cast<const h8*>(bb + (uint32_t)(2 * (16 + q)) * kPfRow);
+                h8 ah, al;
+                __builtin_memcpy(&ah, &ring[q][0], 16);
+                __builtin_memcpy(&al, &ring[q][1], 16);
+                if (step + 16 < nstep) { ring[q][0] = ap[(size_t)(step + 16) * 512]; ring[q][1] = ap[(size_t)(step + 16) * 512 + 64]; }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+            }
+        }
+        if (c < 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sm + nxt + dst[i]) = stg[i];
+        }
+        __syncthreads();
+    }
+    // the two K halves meet in LDS (the staging buffers are dead): rows of a lane = logits 32 mt + 16 kg + r
+    float* Lg = reinterpret_cast<float*>(psm);                               // [32 positions][128]
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Lg[n * 128 + 32 * mt + 16 * kg + r] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 32 * mt + 16 * kg + r;
+            Lg[n * 128 + j] = j < kNPIX ? (acc[r] + Lg[n * 128 + j]) * inv_scale + bf[j] : -3.0e38f;
+        }
+    }
+    __syncthreads();
+    const int p = (int)threadIdx.x >> 4, sub = (int)threadIdx.x & 15;        // 16 threads per position, 8 logits each
+    float v[8], m = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { v[q] = Lg[p * 128 + sub + 16 * q]; m = fmaxf(m, v[q]); }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float sum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { v[q] = (sub + 16 * q) < kNPIX ? expf(v[q] - m) : 0.0f; sum += v[q]; }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (b0 + p < batch) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = sub + 16 * q;
+            if (j < kNPIX) policy[(size_t)(b0 + p) * kNPIX + j] = v[q] / sum;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host ------------------------------------------------------------------
 struct LayerCfg { int cin, cout, pcin, CT, KS, PS, gy, pj; };
 // block b: conv1 = layer 2b, conv2 (+ projection) = layer 2b+1.  pcin: channels of the projection input folded into this
@@ -688,18 +925,36 @@ float pick_scale(const std::vector<float>& a, const std::vector<float>* b) {
     return std::ldexp(1.0f, 13 - e);        // mx * scale in [4096, 8192): 8x below the fp16 maximum
 }
 
-template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ = 0>
+
+// MFMA row m of a 32-row tile -> the output it carries, such that a lane's 16 accumulator rows are 16 consecutive outputs
+inline int row_perm(int m) { return 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3); }
+
+template <class F>
+std::vector<_Float16> pack_frags(int nfrag, F&& val) {          // [fragment][hi|lo][lane][8], val(fragment, lane, e) already scaled
+    std::vector<_Float16> out((size_t)nfrag * 2 * 64 * 8);
+    for (int f = 0; f < nfrag; ++f)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+                const float v = val(f, lane, e);
+                const _Float16 h = (_Float16)v;
+                out[(((size_t)f * 2 + 0) * 64 + lane) * 8 + e] = h;
+                out[(((size_t)f * 2 + 1) * 64 + lane) * 8 + e] = (_Float16)(v - (float)h);
+            }
+    return out;
+}
+
+template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ = 0, int HD = 0>
 int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     constexpr int NT = 4 / PS;
     const size_t lds = kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 * (PJ == 1 ? 2 : 1) : 0);
     static bool attr = false;
     if (!attr) {
-        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ>),
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     const int gx = std::max(1, std::min(a.batch, ncu / gy));
-    hipLaunchKernelGGL((af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ>), dim3(gx, gy), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>), dim3(gx, gy), dim3(256), lds, st, a);
     return 0;
 }
 
@@ -718,6 +973,11 @@ struct f16s_net {
     float inv_scale[10] = {}, inv_scale_p[10] = {};
     // S32 activations: f0, then per block g (conv1 output) and o (block output; blocks 2 and 4 end in fp32 planes)
     char *f0 = nullptr, *g[5] = {}, *o[5] = {};
+    // fused head inputs + dense layers (value = 0, policy = 1)
+    uint4 *hcw[2] = {}, *hfw[2] = {};     // 1x1 conv A fragments; dense A fragments
+    float *hcb[2] = {}, *hfb[2] = {}, *v2w = nullptr, *v2b = nullptr;
+    float hc_inv[2] = {}, hf_inv[2] = {};
+    char* hx[2] = {};
     int abl = 0;
 };
 
@@ -787,6 +1047,53 @@ int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::s
         rc = act(&n->g[b], kLayers[2 * b].cout);
         if (!rc && b != 2 && b != 4) rc = act(&n->o[b], kLayers[2 * b + 1].cout);
     }
+    if (!rc) {          // heads: value/conv [32][4], value/fc1 [4*121][64], value/fc2 [64][1]; policy/conv [32][16], policy/fc [16*121][121]
+        const char* cname[2] = {"value/conv", "policy/conv"};
+        const int nco[2] = {4, 16};
+        for (int h = 0; h < 2 && !rc; ++h) {
+            const std::vector<float>& wc = get(std::string(cname[h]) + "/kernel");
+            const float sc = pick_scale(wc, nullptr);
+            const int NC = nco[h];
+            const std::vector<_Float16> pk = pack_frags(2, [&](int st_, int lane, int e) -> float {
+                const int m = lane & 31, co = m < 16 ? 8 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3) : 99, ci = 16 * (lane >> 5) + 8 * st_ + e;
+                return co < NC ? wc[(size_t)ci * NC + co] * sc : 0.0f;
+            });
+            rc = dev_upload(n->allocs, &n->hcw[h], pk.data(), pk.size() * 2);
+            std::vector<float> bpad(16, 0.0f);
+            const std::vector<float>& bc = get(std::string(cname[h]) + "/bias");
+            for (int i = 0; i < NC; ++i) bpad[i] = bc[i];
+            if (!rc) rc = dev_upload(n->allocs, &n->hcb[h], bpad.data(), 64);
+            n->hc_inv[h] = 1.0f / sc;
+            void* q = nullptr;
+            const size_t bytes = (size_t)max_batch * (h == 0 ? 2048 : 8192);
+            if (!rc) { FS_HIP_OK(hipMalloc(&q, bytes)); FS_HIP_OK(hipMemset(q, 0, bytes)); n->allocs.push_back(q); n->hx[h] = (char*)q; }   // pixels 121..127 stay zero
+        }
+        if (!rc) {
+            const std::vector<float>& w1 = get("value/fc1/kernel");
+            const float sc = pick_scale(w1, nullptr);
+            const std::vector<_Float16> pk = pack_frags(31 * 2, [&](int f, int lane, int e) -> float {
+                const int s_ = f >> 1, mt = f & 1, px = 4 * s_ + 2 * (lane >> 5) + (e >> 2), ch = e & 3, j = 32 * mt + row_perm(lane & 31);
+                return px < kNPIX ? w1[(size_t)(ch * kNPIX + px) * 64 + j] * sc : 0.0f;
+            });
+            rc = dev_upload(n->allocs, &n->hfw[0], pk.data(), pk.size() * 2);
+            n->hf_inv[0] = 1.0f / sc;
+            if (!rc) rc = dev_upload(n->allocs, &n->hfb[0], get("value/fc1/bias").data(), 64 * 4);
+            if (!rc) rc = dev_upload(n->allocs, &n->v2w, get("value/fc2/kernel").data(), 64 * 4);
+            if (!rc) rc = dev_upload(n->allocs, &n->v2b, get("value/fc2/bias").data(), 4);
+        }
+        if (!rc) {
+            const std::vector<float>& wf = get("policy/fc/kernel");
+            const float sc = pick_scale(wf, nullptr);
+            const std::vector<_Float16> pk = pack_frags(kNPIX * 4, [&](int f, int lane, int e) -> float {
+                const int px = f >> 2, mt = f & 3, c16 = 8 * (lane >> 5) + e, j = 32 * mt + row_perm(lane & 31);
+                return j < kNPIX ? wf[(size_t)(c16 * kNPIX + px) * kNPIX + j] * sc : 0.0f;
+            });
+            rc = dev_upload(n->allocs, &n->hfw[1], pk.data(), pk.size() * 2);
+            n->hf_inv[1] = 1.0f / sc;
+            if (!rc) rc = dev_upload(n->allocs, &n->hfb[1], get("policy/fc/bias").data(), kNPIX * 4);
+        }
+        if (!rc) FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_policy_fc_f16s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPfLds));
+    }
     if (rc) { f16s_destroy(n); return rc; }
     *out = n;
     return 0;
@@ -802,8 +1109,10 @@ void f16s_destroy(f16s_net* n) {
 void f16s_set_ablation(f16s_net* n, int bits) { if (n) n->abl = bits; }
 
 static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, const char* in2, char* out, float* out32, int batch,
-                        int WP, int PP) {
+                        int WP, int PP, int head = -1) {
     F16sArgs a;
+    a.hw = nullptr; a.hbias = nullptr; a.hx = nullptr; a.inv_scale_h = 1.0f;
+    if (head >= 0) { a.hw = n->hcw[head]; a.hbias = n->hcb[head]; a.hx = n->hx[head]; a.inv_scale_h = n->hc_inv[head]; }
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
     a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xff) | (li << 8);
     a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
@@ -814,11 +1123,13 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
         case 2: return launch_cfg<2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
         case 3: return launch_cfg<4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
         case 4: return launch_cfg<4, 0, 1, 2, 2, false, false, 1>(st, a, 1, n->ncu);   // (no XACC: weights + projection weights + 3 accumulator sets would spill)
-        case 5: return launch_cfg<1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);      // (one pixel tile per wave, whole K: no k-split exchange)
+        case 5: return head == 0 ? launch_cfg<1, 0, 1, 1, 4, true, true, 2, 1>(st, a, 1, n->ncu)
+                                 : launch_cfg<1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);   // (one pixel tile per wave, whole K: no k-split exchange)
         case 6: return launch_cfg<4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
         case 7: return launch_cfg<2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
         case 8: return launch_cfg<2, 0, 1, 1, 4, false, true, 1>(st, a, 1, n->ncu);
-        default: return launch_cfg<1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
+        default: return head == 1 ? launch_cfg<1, 0, 1, 1, 4, true, true, 2, 2>(st, a, 1, n->ncu)
+                                  : launch_cfg<1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
     }
 }
 
@@ -836,17 +1147,23 @@ int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes, int batch) {
     return rc;
 }
 
-int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3, int WP, int PP) {
+int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3, int WP, int PP, float* value) {
     int rc = launch_layer(n, st, 4, n->o[1], nullptr, n->g[2], nullptr, batch, 0, 0);
-    if (!rc) rc = launch_layer(n, st, 5, n->g[2], n->o[1], nullptr, o3, batch, WP, PP);
+    if (!rc) rc = launch_layer(n, st, 5, n->g[2], n->o[1], nullptr, o3, batch, WP, PP, value ? 0 : -1);
+    if (!rc && value)
+        hipLaunchKernelGGL(af_value_fc_f16s, dim3((batch + 31) / 32), dim3(128), 0, st, n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b,
+                           n->hf_inv[0], value, batch);
     return rc;
 }
 
-int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP, int PP) {
+int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP, int PP, float* policy) {
     int rc = launch_layer(n, st, 6, n->o[1], nullptr, n->g[3], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 7, n->g[3], n->o[1], n->o[3], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 8, n->o[3], nullptr, n->g[4], nullptr, batch, 0, 0);
-    if (!rc) rc = launch_layer(n, st, 9, n->g[4], n->o[3], nullptr, o5, batch, WP, PP);
+    if (!rc) rc = launch_layer(n, st, 9, n->g[4], n->o[3], nullptr, o5, batch, WP, PP, policy ? 1 : -1);
+    if (!rc && policy)
+        hipLaunchKernelGGL(af_policy_fc_f16s, dim3((batch + 31) / 32), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
+                           n->hf_inv[1], policy, batch);
     return rc;
 }
 

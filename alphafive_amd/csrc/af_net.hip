@@ -1280,6 +1280,7 @@ static int g_phead = 1;          // 1: af_policy_head_mfma for boards up to 11x1
 static int g_branch = 1;         // 1: value branch on a side stream
 static int g_substreams = 1;     // >1: split the batch into that many sub-batches, one HIP stream each
 static int g_subbatch = 0;       // 0: batch / g_substreams
+static int g_fhead = 1;          // 1: split-operand path computes the heads itself (fused 1x1 conv + MFMA dense layers); 0: af_value_head / af_policy_head_mfma
 static int g_seqsub = 1;         // >1: that many sequential sub-batches on the caller's stream (Infinity-Cache residency experiment)
 
 // forward pass of positions [b0, b0+batch) on stream st
@@ -1316,8 +1317,8 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
         }
         hipStream_t st = (i == 2) ? vs : st_main;
         if (split16) {
-            if (i == 2 && f16s_value_branch(n->f16s, st, batch, o[2], WP, PP)) return AF_NET_ERR_HIP;
-            if (i == 4 && f16s_policy_branch(n->f16s, st, batch, o[4], WP, PP)) return AF_NET_ERR_HIP;
+            if (i == 2 && f16s_value_branch(n->f16s, st, batch, o[2], WP, PP, g_fhead ? value : nullptr)) return AF_NET_ERR_HIP;
+            if (i == 4 && f16s_policy_branch(n->f16s, st, batch, o[4], WP, PP, g_fhead ? policy : nullptr)) return AF_NET_ERR_HIP;
         } else if (g_wino) {
             // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
             launch_wino(st, n, batch, block_in[i], n->wino1_u[i], n->wino1_ul[i], b.cin, nullptr, nullptr, 0,
@@ -1338,12 +1339,15 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
             launch_conv(st, a);
         }
         if (i == 2) {
+            if (!(split16 && g_fhead))
             hipLaunchKernelGGL(af_value_head, dim3((batch + VPB - 1) / VPB), dim3(256), 0, st, o[2], n->vc_w, n->vc_b, n->v1_w, n->v1_b,
                                n->v2_w, n->v2_b, value, batch, S, WP, PP);
             if (vs != st_main) NET_HIP_OK(hipEventRecord(n->ev_value, vs));
         }
     }
-    if (HW <= 128 && g_phead) {
+    if (split16 && g_fhead) {
+        // (the policy head ran inside f16s_policy_branch)
+    } else if (HW <= 128 && g_phead) {
         const int K = 16 * HW, KS = K + ((2 - K % 32) + 32) % 32;
         const size_t lds = (size_t)16 * KS * 4;
         hipLaunchKernelGGL(af_policy_head_mfma, dim3((batch + 15) / 16), dim3(256), lds, st, o[4], n->pc_w, n->pc_b, n->pf_w,
@@ -1415,7 +1419,8 @@ int af_net_tune(int32_t cout_pad, int32_t shape) {
     if (cout_pad == 5) { g_phead = shape; return AF_NET_OK; }                       // 5: MFMA policy head (1/0)
     if (cout_pad == 4) { g_branch = shape; return AF_NET_OK; }                      // 4: value branch on a side stream (1/0)
     if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)
-    if (cout_pad == 8) { g_seqsub = shape < 1 ? 1 : shape; return AF_NET_OK; }        // 8: sequential sub-batches
+    if (cout_pad == 8) { g_seqsub = shape < 1 ? 1 : shape; return AF_NET_OK; }
+    if (cout_pad == 9) { g_fhead = shape ? 1 : 0; return AF_NET_OK; }                 // 9: heads on the split-operand path (1/0)        // 8: sequential sub-batches
     if (cout_pad == 7) { g_f16s_abl = shape; return AF_NET_OK; }                      // 7: ablation bits of af_conv_f16s (profiling)
     if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
     if (cout_pad == 2) { g_subbatch = shape; return AF_NET_OK; }                     // 2: sub-batch size (0 = batch/streams)
