@@ -99,8 +99,19 @@ def test_alternate_conv_paths_agree_with_fp64():
             p, v = pv(xt)
             assert np.abs(v[:32].cpu().numpy() - v64).max() < 1e-5, mode
             assert np.abs(p[:32].cpu().numpy() - p64).max() < 1e-5, mode
+        # ... and the split-operand path with the r1 head kernels on fp32 planes instead of its own fused heads (af_net_tune(9, 0)),
+        # plus slot independence of the default path: a position's outputs do not depend on where in the batch it sits
+        net_hip.tune(9, 0)
+        p, v = pv(xt)
+        assert np.abs(v[:32].cpu().numpy() - v64).max() < 1e-5 and np.abs(p[:32].cpu().numpy() - p64).max() < 1e-5
+        net_hip.tune(9, 1)
+        p, v = (t.clone() for t in pv(xt))
+        perm = torch.randperm(70, generator=torch.Generator().manual_seed(1)).cuda()
+        pp, vp = pv(xt[perm].contiguous())
+        assert torch.equal(pp, p[perm]) and torch.equal(vp, v[perm])
     finally:
         net_hip.tune(0, 5)
+        net_hip.tune(9, 1)
 
 
 def test_hip_evaluator_follows_weight_updates():
