@@ -148,10 +148,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     };
     const uint32_t nslabs = (uint32_t)((A.batch - pos0 + (int)gridDim.x - 1) / (int)gridDim.x) * SPP;
 
-    // slack, ring slots (their pad units stay zero for the whole launch) and the zero region
-    for (uint32_t u = threadIdx.x; u < (kZoff + kSlabB) / 16; u += 256) *reinterpret_cast<uint4*>(smem + u * 16) = uint4{0, 0, 0, 0};
-    __syncthreads();
-    if (threadIdx.x < CT * 32) reinterpret_cast<float*>(smem + kBiasOff)[threadIdx.x] = A.bias[(int)blockIdx.y * CT * 32 + threadIdx.x];
+    // Start-up (5-8 us of every launch, r2_39): the longest latencies first — the first kDist slabs (HBM -> LDS-DMA), then the
+    // weights (L2) — and under them the LDS zeroing: only what LDS-DMA never writes (slack, the pad units 0..7 and 136..143 of
+    // every unit row of every ring slot, the zero region), so it needs no ordering against the DMA
 #pragma unroll
     for (int d = 0; d < kDist; ++d) {
         if ((uint32_t)d < nslabs) {
@@ -190,6 +189,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
         for (int r = 0; r < 8; ++r) hb[r] = A.hbias[8 * kg + r];
     }
+    if (threadIdx.x < kLds0 / 16) *reinterpret_cast<uint4*>(smem + threadIdx.x * 16) = uint4{0, 0, 0, 0};
+    for (uint32_t u = threadIdx.x; u < (uint32_t)kRing * 128u; u += 256) {      // (slot, unit row 0..7, side, unit 0..7)
+        const uint32_t off = kLds0 + (u >> 7) * kSlabB + ((u >> 4) & 7u) * kRowB + (((u >> 3) & 1u) ? 136u * 16u : 0u) + (u & 7u) * 16u;
+        *reinterpret_cast<uint4*>(smem + off) = uint4{0, 0, 0, 0};
+    }
+    for (uint32_t u = threadIdx.x; u < kSlabB / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
+    if (threadIdx.x < CT * 32) reinterpret_cast<float*>(smem + kBiasOff)[threadIdx.x] = A.bias[(int)blockIdx.y * CT * 32 + threadIdx.x];
     // lane geometry per pixel tile: LDS byte base of tap (0,0) in slot 0, zero-region twin, output unit
     uint32_t lb[NT], zb[NT];
     int pix[NT];
