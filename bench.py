@@ -177,6 +177,58 @@ def copy_bandwidth_gbs(dev, mib=1024, reps=10):
     return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def live_net_traffic(G, ticks=400, last=200, timeout_s=180):
+    """HBM bytes per net forward from the PMC counters, collected now: rocprofv3 --kernel-trace --pmc <one counter> (kernel trace
+    only, one pass per counter: MI355X_MICROARCH.md) around tools/probe_tick_min.py in a child process.  None if rocprofv3 is
+    missing or a pass fails (the caller then keeps the committed profile's figure)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="af_pmc_", dir="/tmp")
+    per_kernel = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            env = dict(os.environ, TICKS=str(ticks), G=str(G), TMPDIR="/tmp")
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.join(REPO, "tools", "probe_tick_min.py")], cwd="/tmp", env=env, timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None
+            cur = sqlite3.connect(dbs[0]).cursor()
+            cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+            name_col = "kernel_name" if "kernel_name" in cols else "name"
+            vals = {}
+            for k, c, v in cur.execute(f"select {name_col}, counter_name, value from counters_collection order by dispatch_id"):
+                if c == ctr:
+                    vals.setdefault(k, []).append(v)
+            if not vals:
+                return None
+            for k, vs in vals.items():
+                per_kernel.setdefault(k, {})[ctr] = (sum(vs[-last:]) / len(vs[-last:]), len(vs))
+        tick = [k for k in per_kernel if "af_tick_kernel" in k]
+        if not tick or "FETCH_SIZE" not in per_kernel[tick[0]]:
+            return None
+        n_tick = per_kernel[tick[0]]["FETCH_SIZE"][1]
+        total = 0.0
+        for k, c in per_kernel.items():
+            if k in tick or "af_pack" in k or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                continue
+            if not ("af_" in k):                       # torch fill / copy kernels of the probe's set-up
+                continue
+            total += round(c["FETCH_SIZE"][1] / n_tick) * (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0
+        return int(total) if total > 0 else None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -190,6 +242,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic from profiles/ instead of two rocprofv3 counter passes in this run")
     ap.add_argument("--pipe-values", action="store_true",
                     help="W / Q in fp64: the arithmetic of main.py's pipe-fed workers (networkAPI.py:72); default = the pv_fn path")
     ap.add_argument("--net", default="hip", choices=["hip", "torch", "deep-bf16", "deep-bf16-torch"],
@@ -361,6 +414,16 @@ def main():
                 traffic_net = prof["net_forward_bytes_per_launch"]["corrected"]
                 traffic_tick = prof["tick_kernel_bytes_per_launch"]["corrected"]
                 traffic_src = "profiles/r2_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                # ... and, unless --no-pmc, collected again in THIS run: two short rocprofv3 counter passes over the same kernels
+                # (child processes, after the timed region; the net's traffic does not depend on the game phase, the tick
+                # kernel's does, so tree_roofline keeps the steady-state figure of the file)
+                live = None if (args.no_pmc or world > 1) else live_net_traffic(G)
+                if live is not None:
+                    traffic_net = live
+                    traffic_src = ("this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
+                                   "tools/probe_tick_min.py, bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the forward's "
+                                   "kernels, mean of the last 200 dispatches; profiles/r2_pmc_hbm_traffic.json has %.3f GB"
+                                   % (prof["net_forward_bytes_per_launch"]["corrected"] / 1e9))
         if deep is not None:
             roof = ({"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
                      "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"} if args.net.endswith("torch") else
