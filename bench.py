@@ -188,6 +188,9 @@ def live_net_traffic(G, ticks=400, last=200, timeout_s=180):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    # not inside another profiler session (bench.py itself run under rocprofv3 / rocprof-sys): no nested tool registration
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFSYS")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     tmp = tempfile.mkdtemp(prefix="af_pmc_", dir="/tmp")
     per_kernel = {}
     try:
