@@ -69,8 +69,8 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x)
 #ifdef AF_F16S_TIMING
 // profiling build only (tools/probe_f16s_timing.py): cycles per phase, [layer][workgroup (x + 256 y)][wave][phase]
 // phase 0 items (MFMA + reads + DMA issue), 1 vmcnt waits, 2 slab barriers, 3 k-split exchange (7: its barrier alone), 4 epilogue,
-// 5 total, 6 positions
-__device__ unsigned long long g_f16s_cycles[10][512][4][8];
+// 5 total, 6 positions; 8 start-up (kernel entry -> weights and first slabs in place)
+__device__ unsigned long long g_f16s_cycles[10][512][4][9];
 #define AF_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define AF_TACC(slot, a, b) tacc[slot] += (b) - (a)
 #else
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
     int pos = blockIdx.x;
     if (pos >= A.batch) return;
+    AF_T(t_entry);
 
     // slab j of a position: the NSP slabs of the projection input first, then the NSM slabs of the 3x3 input (the other
     // order — long slabs first, so that the epilogue's stores have more time before the next wait on vmcnt — measured
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    AF_T(t_ready);
 
     // B fragment of an item (k-step c, tap) of a projection / main slab, half p, for the pixel tile whose centre / left /
     // right read bases are given
@@ -544,6 +546,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         tacc[0] = tacc[5] - tacc[1] - tacc[2] - tacc[3] - tacc[4];
         const int layer = (A.abl >> 8) & 15;
         for (int q = 0; q < 8; ++q) g_f16s_cycles[layer][blockIdx.x + 256 * blockIdx.y][wv][q] = tacc[q];
+        g_f16s_cycles[layer][blockIdx.x + 256 * blockIdx.y][wv][8] = t_ready - t_entry;
     }
 #endif
 }
@@ -1197,7 +1200,7 @@ int f16s_read_activation(f16s_net* n, int which, int batch, float* host) {
 #ifdef AF_F16S_TIMING
 extern "C" int af_f16s_debug_cycles(unsigned long long* host) {
     FS_HIP_OK(hipDeviceSynchronize());
-    FS_HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_f16s_cycles), sizeof(unsigned long long) * 10 * 512 * 4 * 8));
+    FS_HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_f16s_cycles), sizeof(unsigned long long) * 10 * 512 * 4 * 9));
     return 0;
 }
 #endif

@@ -26,20 +26,20 @@ for _ in range(3):
     hn(xb)
 torch.cuda.synchronize()
 L = net_hip.lib()
-buf = np.zeros((10, 512, 4, 8), np.uint64)
+buf = np.zeros((10, 512, 4, 9), np.uint64)
 L.af_f16s_debug_cycles.argtypes = [C.POINTER(C.c_uint64)]
 assert L.af_f16s_debug_cycles(buf.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
 names = ["L1 32->64", "L2 64->64+p32", "L3 64->128", "L4 128->128+p64", "L5 128->32 (+proj out)", "L6 32->32 (+proj in)", "L7 128->64",
          "L8 64->64+p128", "L9 64->32 (+proj out)", "L10 32->32 (+proj in)"]
 print("%-24s %6s %9s | %% of wave cycles: %7s %7s %7s %7s %7s %7s" % ("layer", "pos/WG", "cyc/pos", "items", "vmcnt", "barrier", "exchg", "(xbar)", "epilog"))
 for li in range(10):
-    d = buf[li].reshape(-1, 8).astype(np.float64)
+    d = buf[li].reshape(-1, 9).astype(np.float64)
     d = d[d[:, 6] > 0]
     tot = d[:, 5].sum()
     print("%-24s %6.1f %9.0f | %25.1f %7.1f %7.1f %7.1f %7.1f %7.1f" % (names[li], d[:, 6].mean(), tot / d[:, 6].sum(),
           100 * d[:, 0].sum() / tot, 100 * d[:, 1].sum() / tot, 100 * d[:, 2].sum() / tot, 100 * d[:, 3].sum() / tot, 100 * d[:, 7].sum() / tot,
           100 * d[:, 4].sum() / tot))
-    w = buf[li].reshape(-1, 4, 8).astype(np.float64)
+    w = buf[li].reshape(-1, 4, 9).astype(np.float64)
     w = w[w[:, 0, 6] > 0]
     print("      per wave: items %s  epilogue %s  exch-barrier %s (cycles per position)" % tuple(
         np.round(w[:, :, q].sum(0) / w[:, :, 6].sum(0)).astype(int).tolist() for q in (0, 4, 7)))
