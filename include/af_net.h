@@ -49,7 +49,10 @@ int af_net_forward(af_net* n, void* stream, const float* planes_dev, int32_t bat
  *   key 1: number of sub-batch side streams (default 1)      key 2: sub-batch size (0 = batch / streams)
  *   key 3: ablation variant of the Winograd kernel (profiling only; results are wrong by design)
  *   key 4: value branch on a side stream (default 1)         key 5: MFMA policy head (default 1)
- *   key 6: workgroups of the persistent variant (default 256)   key 7: ablation bits of path 5 (profiling) */
+ *   key 6: workgroups of the persistent variant (default 256)   key 7: ablation bits of path 5 (profiling)
+ *   key 8: sequential sub-batches on one stream (default 1 = none; measured slower)
+ *   key 9: path 5 computes the heads itself — 1x1 head convolutions fused into the last conv of each branch, dense layers on
+ *          the same split-operand MFMA (default 1); 0 = the fp32 head kernels of the other paths on fp32 planes */
 int af_net_tune(int32_t key, int32_t value);
 
 /* Tests / debugging of the fp16 split-operand path (conv path 5, 11x11 boards): intermediate activation `which`
