@@ -62,6 +62,7 @@ struct EngineParams {
     int32_t* free_idx;    // [G][cap] stack of free slots below the high-water mark `nodes`
     int32_t* edge_n;
     float *edge_w, *edge_p;
+    int32_t* edge_c;      // [G][cap][CP] child cache: node index + 1 of the position reached by playing that cell, 0 = not known yet
     double* edge_w64;     // AF_MODE_VALUE_F64 (pipe path, networkAPI.py:72): W as a python float; edge_w is then unused
     int32_t w64;
     // finished-episode double buffers
@@ -273,6 +274,18 @@ __device__ float pairwise_sum(const float* a, int n) {   // n <= 256
 #ifndef AF_TICK_MIN_WAVES
 #define AF_TICK_MIN_WAVES 4   // 4 one-wave workgroups per SIMD = 16 games per CU in flight (measured 0.075 vs 0.088 ms per tick at 3)
 #endif
+#ifdef AF_TICK_TIMING
+// profiling build only (tools/probe_tick_timing.py): shader cycles of the last launch per game and phase —
+// 0 state load, 1 consume (expand + backup), 2 move boundary (calc_policy, record, collector), 3 terminal test + store lookup,
+// 4 select (rows, noise, score, argmax, step), 5 park / yield + state store, 6 total, 7 selects
+__device__ unsigned long long g_tick_cycles[8192][8];
+#define TK_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define TK_ACC(slot, a, b) tk[slot] += (b) - (a)
+#else
+#define TK_T(var)
+#define TK_ACC(slot, a, b)
+#endif
+
 template <int KW, bool W64>
 __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EngineParams P, const float* __restrict__ policy_in,
                                                      const float* __restrict__ value_in, float* __restrict__ planes_out) {
@@ -286,6 +299,10 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     int phase = rfli(P.phase[g]);
     if (phase == PH_IDLE || phase == PH_MOVE_DONE || phase == PH_ERROR) return;
     const u64 t_start = wall_clock64();
+#ifdef AF_TICK_TIMING
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TK_T(tk_entry);
 
     // ---- load game state (wave-uniform) ----
     u64 root_m[KW], root_t[KW];
@@ -318,6 +335,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     float* const ew = P.edge_w + (w64 ? (size_t)0 : (size_t)g * NCAP * CP);
     double* const ew64 = P.edge_w64 + (w64 ? (size_t)g * NCAP * CP : (size_t)0);
     float* const ep = P.edge_p + (size_t)g * NCAP * CP;
+    int32_t* const ec = P.edge_c + (size_t)g * NCAP * CP;
     uint32_t* const slots = P.hash + (size_t)g * (P.hash_mask + 1);
     int32_t* const pnode = P.path_node + (size_t)g * CP;
     int32_t* const pcell = P.path_cell + (size_t)g * CP;
@@ -340,6 +358,8 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         __syncthreads();
     };
 
+    TK_T(tk_loaded);
+    TK_ACC(0, tk_entry, tk_loaded);
     // ---- 1. consume the evaluation of the parked leaf: player.py:186-202 + :166 ----
     if (rfli(P.pending[g])) {
         u64 lm[KW], lt[KW], legal[KW];
@@ -371,11 +391,16 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             int idx;
             if (nfree > 0) idx = rfli(fre[--nfree]); else idx = nodes++;
             if (lane < 2 * KW) nkeys[(size_t)idx * 2 * KW + lane] = key_word<KW>(lm, lt, lane);
-            if (lane == 0) { nsum[idx] = 0; slots[slot] = (uint32_t)idx + 1u; }
+            if (lane == 0) {
+                nsum[idx] = 0; slots[slot] = (uint32_t)idx + 1u;
+                // child cache of the parent edge (see the descent below): the move that led here now has a node
+                if (depth > 0) ec[(size_t)pnode[depth - 1] * CP + pcell[depth - 1]] = idx + 1;
+            }
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
                 const size_t off = (size_t)idx * CP + lane + 64 * k;
                 en[off] = 0;
+                ec[off] = 0;
                 if (w64) ew64[off] = 0.0; else ew[off] = 0.0f;
                 ep[off] = ((legal[k] >> lane) & 1ull) ? pk[k] / s : 0.0f;
             }
@@ -392,8 +417,11 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     bool parked = false;
     int work = 0;   // selects done in this launch
 
+    TK_T(tk_consumed);
+    TK_ACC(1, tk_loaded, tk_consumed);
     // ---- 2. advance until the game parks ----
     while (!parked && !err) {
+        TK_T(tk_iter);
         // A launch lasts as long as its slowest game.  Simulations that end in a terminal position need no
         // evaluation, so a game whose root has a decided child could run hundreds of them back to back while
         // every other wave has long parked; after `budget` selects the game yields at the next simulation
@@ -611,6 +639,8 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             continue;
         }
 
+        TK_T(tk_sim);
+        TK_ACC(2, tk_iter, tk_sim);
         // ------------- one simulation: player.py:204-228 MCTS_search -------------
         u64 cm[KW], ctb[KW];
         int last, depth;
@@ -627,7 +657,22 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             for (int k = 0; k < KW; ++k) { cm[k] = root_m[k]; ctb[k] = root_t[k]; }
             last = root_last; depth = 0;
         }
+        // Child cache: an edge remembers the node its move leads to, so a descent follows indices instead of probing the hash and
+        // comparing keys at every level (two dependent memory round trips per select).  A cached index stays valid for as long
+        // as its parent lives: the collector only drops nodes whose stones are not a superset of the root's, a child has its
+        // parent's stones plus one, so a surviving parent's children all survive; dropped slots are reused only for new nodes,
+        // whose rows (cache included) are initialised at expansion; a whole-tree reset drops every node.
+        int hint = 0, pidx = -1, pcl = 0;
+        // ... and the child's rows are requested as soon as its index is known (right after the argmax), so that they travel
+        // while the move is played and the terminal test runs
+        typedef typename std::conditional<W64, double, float>::type wrow_t;
+        int32_t r_raw[KW], r_c[KW];
+        float r_p[KW];
+        wrow_t r_w[KW];
+        int32_t r_sum = 0;
+        bool r_have = false;
         for (;;) {
+            TK_T(tk_a);
             float tv;
             if (terminal_test<KW>(P, cm, ctb, &tv)) {                       // :213-217
                 backup(depth, tv, 0);
@@ -635,8 +680,14 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 sims_left--;
                 break;
             }
-            uint32_t slot;
-            const int idx = tree_lookup<KW>(P, g, cm, ctb, lane, &slot);
+            uint32_t slot = 0xffffffffu;
+            int idx;
+            if (hint) {
+                idx = hint - 1;
+            } else {
+                idx = tree_lookup<KW>(P, g, cm, ctb, lane, &slot);
+                if (idx >= 0 && pidx >= 0 && lane == 0) ec[(size_t)pidx * CP + pcl] = idx + 1;   // reached through another move order before
+            }
             if (idx < 0) {                                                  // :218 unseen -> park for the net
                 if (lane < 2 * KW) P.leaf[(size_t)g * 2 * KW + lane] = key_word<KW>(cm, ctb, lane);
                 if (lane == 0) { P.depth[g] = depth; P.leaf_last[g] = last; P.leaf_slot[g] = (int32_t)slot; }
@@ -663,26 +714,40 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 phase = PH_DESCENT; status = AF_STATUS_YIELD; parked = true; ct[CT_YIELDS]++;
                 break;
             }
+            TK_T(tk_b);
+            TK_ACC(3, tk_a, tk_b);
             // ------------- player.py:230-279 select_action_q_and_u -------------
             const bool is_root = depth == 0;
             u64 legal[KW];
 #pragma unroll
             for (int k = 0; k < KW; ++k) legal[k] = ~(cm[k] | ctb[k]) & P.boardmask[k];
-            const int sum_n = rfli(nsum[idx]) + 1;                          // :237
+            if (!r_have) {
+                r_sum = nsum[idx];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const size_t off = (size_t)idx * CP + lane + 64 * k;
+                    r_raw[k] = en[off];
+                    r_c[k] = ec[off];
+                    if constexpr (W64) r_w[k] = ew64[off]; else r_w[k] = ew[off];
+                    r_p[k] = ep[off];
+                }
+            }
+            r_have = false;
+            const int sum_n = rfli(r_sum) + 1;                              // :237
             if (lane == 0) nsum[idx] = sum_n;
             const uint32_t sel_id = sel++;
             int nn[KW];
             float pp[KW];
-            typename std::conditional<W64, double, float>::type ww[KW];
+            wrow_t ww[KW];
             bool ff[KW];
+            int32_t cc[KW];
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
-                const size_t off = (size_t)idx * CP + lane + 64 * k;
-                const int32_t raw = en[off];
-                nn[k] = raw & 0x7fffffff;
-                ff[k] = raw < 0;
-                if constexpr (W64) ww[k] = ew64[off]; else ww[k] = ew[off];
-                pp[k] = ep[off];
+                nn[k] = r_raw[k] & 0x7fffffff;
+                ff[k] = r_raw[k] < 0;
+                cc[k] = r_c[k];
+                ww[k] = r_w[k];
+                pp[k] = r_p[k];
             }
             double dd[KW];
             if (P.training) {
@@ -771,6 +836,24 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 cell = bb_select<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1));
             }
             cell = rfli(cell);
+            hint = 0;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { const int t_ = __shfl(cc[k], cell & 63); if ((cell >> 6) == k) hint = t_; }
+            hint = rfli(hint);
+            pidx = idx; pcl = cell;
+            if (hint) {
+                const int ci = hint - 1;
+                r_sum = nsum[ci];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const size_t off = (size_t)ci * CP + lane + 64 * k;
+                    r_raw[k] = en[off];
+                    r_c[k] = ec[off];
+                    if constexpr (W64) r_w[k] = ew64[off]; else r_w[k] = ew[off];
+                    r_p[k] = ep[off];
+                }
+                r_have = true;
+            }
             ++work;
             ct[CT_SELECTS]++;
             ct[CT_LSUM] += (uint32_t)bb_count<KW>(legal);
@@ -787,8 +870,14 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             }
             last = cell;
             __syncthreads();
+            TK_T(tk_c);
+            TK_ACC(4, tk_b, tk_c);
+#ifdef AF_TICK_TIMING
+            tk[7] += 1;
+#endif
         }
     }
+    TK_T(tk_parked);
 
     // ---- 3. store state ----
     if (err) { phase = PH_ERROR; status = err; }
@@ -814,6 +903,14 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         atomicAdd(&P.hist[HIST_TIME + (tb < 31ull ? tb : 31ull)], 1ull);
         atomicMax(&P.hist[HIST_MAXTIME], dt);
     }
+#ifdef AF_TICK_TIMING
+    {
+        TK_T(tk_end);
+        tk[5] = tk_end - tk_parked;
+        tk[6] = tk_end - tk_entry;
+        if (lane == 0 && g < 8192) for (int q = 0; q < 8; ++q) g_tick_cycles[g][q] = tk[q];
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1043,7 +1140,7 @@ int af_engine_create(const af_config* cfg, int32_t num_games, int32_t device, in
     A(visits, G * CP); A(policy, G * CP); A(root, G * 2 * KW); A(leaf, G * 2 * KW); A(tau, G);
     A(episode, G); A(sel, G); A(plyctr, G); A(path_node, G * CP); A(path_cell, G * CP);
     A(hash, G * hcap); A(node_key, G * node_cap * 2 * KW); A(node_sum, G * node_cap); A(free_idx, G * node_cap);
-    A(edge_n, G * node_cap * CP); A(edge_p, G * node_cap * CP);
+    A(edge_n, G * node_cap * CP); A(edge_p, G * node_cap * CP); A(edge_c, G * node_cap * CP);
     if (value_f64) { A(edge_w64, G * node_cap * CP); A(edge_w, 64); } else { A(edge_w, G * node_cap * CP); A(edge_w64, 8); }
     A(ep_seq, G); A(ep_popped, G); A(counters, G * CT_N); A(progress, 2); A(hist, HIST_N);
     if (mode == AF_MODE_SELFPLAY) {
@@ -1417,6 +1514,7 @@ int af_engine_load_tree(af_engine* e, int32_t game, int32_t count, const uint64_
         } else
         HIP_OK(hipMemcpy(P.edge_w + nb * CP, bw.data(), bw.size() * 4, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(P.edge_p + nb * CP, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemset(P.edge_c + nb * CP, 0, (size_t)count * CP * 4));
     }
     int32_t zero = 0;
     HIP_OK(hipMemcpy(P.nodes + game, &count, 4, hipMemcpyHostToDevice));
@@ -1486,6 +1584,14 @@ int af_engine_set_tree_w64(af_engine* e, int32_t game, int32_t count, const doub
     HIP_OK(hipMemcpy(P.edge_w64 + (size_t)game * P.node_cap * CP, bd.data(), bd.size() * 8, hipMemcpyHostToDevice));
     return AF_OK;
 }
+
+#ifdef AF_TICK_TIMING
+int af_engine_debug_tick_cycles(unsigned long long* host) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tick_cycles), sizeof(unsigned long long) * 8192 * 8));
+    return AF_OK;
+}
+#endif
 
 // utils.py:156-175 board_to_state from a key
 int af_key_to_state(const uint64_t* key, int32_t S, char* out, int32_t cap) {
