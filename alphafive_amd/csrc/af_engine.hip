@@ -165,7 +165,10 @@ __device__ __forceinline__ void run_mask(const u64* b, int d, int goal, const u6
 
 // utils.py:199-235 is_game_over on bitboards.  Scan order of the reference (cell-major,
 // then down / right / diag-down-right / diag-up-right) decides when both colours have a line.
-template <int KW>
+// MOVED: the position was reached by a move from a position that was not terminal (every position of a descent: its parent was
+// tested one level up, the root at the start of the move), so the side to move cannot own a line — only the stones of the side
+// that has just moved are scanned (half the work; the result is the same)
+template <int KW, bool MOVED = false>
 __device__ int terminal_test(const EngineParams& P, const u64* mine, const u64* theirs, float* value) {
     int best_key = 0x7fffffff;
     float best_v = 0.0f;
@@ -175,7 +178,12 @@ __device__ int terminal_test(const EngineParams& P, const u64* mine, const u64* 
         u64 wm[KW], wt[KW], any[KW];
         const int d = dir == 0 ? S : (dir == 1 ? 1 : (dir == 2 ? S + 1 : S - 1));
         const u64* valid = dir == 0 ? nullptr : P.colmask;
-        if (dir == 3) {
+        if (MOVED) {
+#pragma unroll
+            for (int k = 0; k < KW; ++k) wm[k] = 0;
+            if (dir == 3) run_mask<KW, true>(theirs, d, P.goal, valid, wt);
+            else run_mask<KW, false>(theirs, d, P.goal, valid, wt);
+        } else if (dir == 3) {
             run_mask<KW, true>(mine, d, P.goal, valid, wm);
             run_mask<KW, true>(theirs, d, P.goal, valid, wt);
         } else {
@@ -377,13 +385,19 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             const int c = lane + 64 * k;
             pk[k] = ((legal[k] >> lane) & 1ull) ? policy_in[(size_t)g * C + c] : 0.0f;
         }
-        // all_p: left-to-right fp32 sum in row-major legal order (SURVEY §8a rule 1)
+        // all_p: left-to-right fp32 sum in row-major legal order (SURVEY §8a rule 1; the zeros of the occupied cells change nothing).
+        // Every lane adds the same broadcast LDS values in the same order: a chain of 64 KW dependent adds with the operands
+        // fetched four at a time, instead of a v_readlane + hazard + add per cell
+#pragma unroll
+        for (int k = 0; k < KW; ++k) s_pv[lane + 64 * k] = pk[k];
+        __syncthreads();
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < KW; ++k) {
-#pragma unroll
-            for (int l = 0; l < 64; ++l) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk[k]), l));
+        for (int i = 0; i < CP; i += 4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(&s_pv[i]);
+            s = s + v4.x; s = s + v4.y; s = s + v4.z; s = s + v4.w;
         }
+        s = rflf(s);
         if (!((double)s >= 1e-5)) s = (float)1e-5;
         if ((nfree == 0 && nodes >= NCAP) || slot == 0xffffffffu) {
             err = AF_ERR_NODE_CAP;
@@ -674,7 +688,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         for (;;) {
             TK_T(tk_a);
             float tv;
-            if (terminal_test<KW>(P, cm, ctb, &tv)) {                       // :213-217
+            if (terminal_test<KW, true>(P, cm, ctb, &tv)) {                 // :213-217
                 backup(depth, tv, 0);
                 ct[CT_TERMINALS]++; ct[CT_SIMS]++;
                 sims_left--;
@@ -895,7 +909,9 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         P.sel[g] = sel;
         P.plyctr[g] = plyctr;
         P.status[g] = status;
-        for (int i = 0; i < CT_N; ++i) P.counters[(size_t)g * CT_N + i] += (u64)ct[i];
+        // (fire-and-forget atomics: a read-modify-write would cost this wave one more memory round trip at its very end)
+        for (int i = 0; i < CT_N; ++i)
+            if (ct[i]) atomicAdd(reinterpret_cast<unsigned long long*>(&P.counters[(size_t)g * CT_N + i]), (unsigned long long)ct[i]);
         // launch-shape evidence: selects per launch and the wave's lifetime (100 MHz constant clock)
         const u64 dt = wall_clock64() - t_start;
         atomicAdd(&P.hist[HIST_WORK + (work < 63 ? work : 63)], 1ull);
