@@ -360,11 +360,17 @@ class SelfPlayEngine:
         return self.engine.progress(self.torch.cuda.current_stream(self.dev).cuda_stream)
 
     # ---- finished-episode hand-off: pack on the device, written straight into pinned host memory ----
+    def _pack_plies(self, cap):
+        """Ply capacity of a pack buffer for `cap` episodes: ~40 per episode (they average 26 at 11x11; what does not fit
+        waits for the next post) but never less than ONE maximum-length episode (S*S plies) — af_pack_scan takes a prefix in
+        (game, sequence) order, so an episode longer than the whole buffer would block every later one for ever."""
+        return max(cap * 40, int(self.engine.max_plies))
+
     def _outbox(self, cap):
         box = self._boxes.get(cap)
         if box is None:
             torch = self.torch
-            max_plies = cap * 40                                   # episodes are ~26 plies; what does not fit waits for the next post
+            max_plies = self._pack_plies(cap)
             ints = self.engine.pack_ints(cap, max_plies)
             box = dict(cap=cap, max_plies=max_plies, buf=torch.zeros(ints, dtype=torch.int32, pin_memory=True),
                        event=torch.cuda.Event(), posted=False)
@@ -402,9 +408,9 @@ class SelfPlayEngine:
         key = ("dev", cap)
         buf = self._boxes.get(key)
         if buf is None:
-            buf = self.torch.zeros(self.engine.pack_ints(cap, cap * 40), dtype=self.torch.int32, device=self.dev)
+            buf = self.torch.zeros(self.engine.pack_ints(cap, self._pack_plies(cap)), dtype=self.torch.int32, device=self.dev)
             self._boxes[key] = buf
-        self.engine.pack_episodes(buf.data_ptr(), cap, cap * 40, self.torch.cuda.current_stream(self.dev).cuda_stream)
+        self.engine.pack_episodes(buf.data_ptr(), cap, self._pack_plies(cap), self.torch.cuda.current_stream(self.dev).cuda_stream)
         return buf
 
     def pop_episodes(self, cap=256):

@@ -10,7 +10,10 @@ PyTorch-ROCm: 3xSxS -> (softmax policy[S*S], tanh(x/2) value).
 Same call surface as the reference's ResNet for the self-play path: ResNet(board_size),
 .eval(inputs) -> (prob, value) numpy, .restore(ckpt_path) (reads the TF checkpoint through
 alphafive_amd.tensorbundle, no TensorFlow), .get_pipes(config), .close(), .graph.as_default().
-eval_device() is the on-device entry the batched engine uses (no host round trip).
+On a cuda device .eval() / .eval_device() run the hand-written kernels (libaf_net.so, strictly: a missing library
+raises) — so NetworkAPI's `agent_model.eval(batch)` (networkAPI.py:72), Player(pv_fn=net.eval) and the batched engine
+share one arithmetic.  eval_torch() is the plain PyTorch-op evaluation of the same graph: the fp32 reference the
+kernel tests compare with, the trainer's forward (alphafive_amd/train.py) and the only path of a device="cpu" net.
 Parameters are kept under the checkpoint's variable names in TF layout (HWIO / [in,out]).
 No torch.compile (it would emit Triton).
 """
@@ -79,6 +82,7 @@ class ResNet(object):
         self.api = None
         self.variables = {}
         self._t = {}
+        self._hip_eval = None
         self.set_variables(random_variables(board_size, seed))
 
     # ---- weights ----
@@ -125,8 +129,9 @@ class ResNet(object):
         return F.elu(res + g)
 
     @torch.no_grad()
-    def eval_device(self, x):
-        """x float32[B,3,S,S] on self.device -> (prob float32[B,S*S], value float32[B]) on device."""
+    def eval_torch(self, x):
+        """Plain PyTorch ops (MIOpen convs / hipBLASLt GEMMs on ROCm): x float32[B,3,S,S] on self.device ->
+        (prob float32[B,S*S], value float32[B]).  The reference evaluation, not the product path on a GPU."""
         B = x.shape[0]
         f = self._conv(x, "bone/conv1", True)
         f = self._residual(f, "bone/block1")
@@ -140,6 +145,15 @@ class ResNet(object):
         p = self._conv(p, "policy/conv", True).reshape(B, -1)
         p = torch.softmax(p @ self._t["policy/fc/kernel"] + self._t["policy/fc/bias"], dim=1)
         return p, v
+
+    def eval_device(self, x):
+        """x float32[B,3,S,S] on self.device -> (prob float32[B,S*S], value float32[B]) on device.  cuda: the hand-written
+        kernels (the returned tensors are views of the evaluator's output buffers, valid until the next call)."""
+        if self.device.type == "cuda":
+            if self._hip_eval is None:
+                self._hip_eval = self.select_backend("hip")      # raises without libaf_net.so: no vendor-op fallback
+            return self._hip_eval(x.contiguous())
+        return self.eval_torch(x)
 
     def eval(self, inputs):
         """network.py:90-97: numpy float32[B,3,S,S] -> (prob[B,S*S], value[B]) numpy."""
@@ -164,7 +178,7 @@ class ResNet(object):
         if name != "torch":
             raise ValueError("unknown net backend %r" % (name,))
         self._backend = "torch"
-        return self.eval_device
+        return self.eval_torch
 
     def flops_per_position(self):
         """2*MAC of one forward pass (direct convolution), any board size."""

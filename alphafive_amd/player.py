@@ -79,7 +79,8 @@ class TreeView(Mapping):
 class Player(object):
     _next_game_id = [0]          # process-wide: every Player built without an explicit game_id gets its own noise stream
 
-    def __init__(self, cfg=None, training=True, pipe=None, pv_fn=None, device=0, seed=None, game_id=None, node_cap=0):
+    def __init__(self, cfg=None, training=True, pipe=None, pv_fn=None, device=0, seed=None, game_id=None, node_cap=0,
+                 graph=True):
         assert pipe is not None or pv_fn is not None
         import torch
         # The reference's workers draw from process-global MT19937 streams seeded from OS entropy (main.py:82: N workers each
@@ -112,19 +113,26 @@ class Player(object):
         self._value = torch.zeros((1,), dtype=torch.float32, device=self._dev)
         self._reset_pending = False
         self._adopt = None
+        # pv_fn = ResNet.eval on a cuda device (self_play.py:88, choose_best_player.py:38-40): the leaves stay on the device and
+        # are evaluated by the hand-written kernels straight into the tensors the tick kernel reads — this Player gets its own
+        # evaluator handle (its output buffers are bound to this game).  select_backend("hip") raises when libaf_net.so is
+        # missing or its ABI does not match; nothing falls back to vendor ops.  Any other owner with an eval_device() method
+        # (e.g. DeepResNet) is used as it is.
         owner = getattr(pv_fn, "__self__", None)
-        self._pv_device = getattr(owner, "eval_device", None) if pv_fn is not None else None
+        self._pv_owner = None
+        self._pv_device = None
+        self.backend = "host"                            # evaluations cross the host boundary (numpy pv_fn or pipe)
+        self._use_graph = bool(graph)
         self._graph = None
-        if self._pv_device is not None and hasattr(owner, "select_backend") and getattr(owner, "device", None) is not None \
-                and owner.device.type == "cuda":
-            # pv_fn is ResNet.eval: evaluate leaves with the hand-written kernels, results written straight into the
-            # tensors the tick kernel reads (one position per launch: this path is launch-latency bound, see _search_batch)
-            try:
+        if pv_fn is not None and owner is not None and getattr(pv_fn, "__name__", "") == "eval" \
+                and hasattr(owner, "eval_device") and getattr(getattr(owner, "device", None), "type", None) == "cuda":
+            from .network import ResNet
+            if isinstance(owner, ResNet):
                 fn = owner.select_backend("hip")
                 fn.bind_outputs(self._policy, self._value)
-                self._pv_device = fn
-            except Exception:                            # e.g. libaf_net.so not built: the torch-op evaluator is still a device path
-                pass
+                self._pv_device, self._pv_owner, self.backend = fn, owner, "hip"
+            else:
+                self._pv_device, self.backend = owner.eval_device, "device"
         self.last_visits = None
 
     # -- player.py:37-46
@@ -191,36 +199,40 @@ class Player(object):
         self._policy.copy_(self._torch.from_numpy(np.ascontiguousarray(policy, np.float32).reshape(1, self._C)))
         self._value.copy_(self._torch.from_numpy(np.asarray([value], np.float32)))
 
+    def _weights_version(self):
+        return getattr(self._pv_owner, "version", None)
+
     def _search_batch(self, n=16):
         """n x (tick kernel -> leaf evaluation) without touching the host.  One game is launch-latency bound (14 dependent
-        launches per simulation), so the batch is captured once into a HIP graph and replayed; if capture is not possible
-        the same launches are issued eagerly."""
+        launches per simulation), so the batch is captured once into a HIP graph and replayed.  The graph is keyed on the
+        training flag AND on the owner's weight version: a replay skips the Python evaluator wrapper — the only place that
+        notices net.restore() / load_npz() / set_variables() and re-packs the weights for the kernels — so after a weight
+        update (choose_best_player.py:78-82 reloads both nets between matches) the graph is dropped, one eager evaluation
+        reloads the weights and the batch is captured again.  A failing capture raises (Player(graph=False) is the explicit
+        way to run the same launches eagerly)."""
         torch = self._torch
-        key = bool(self.training)
-        if self._graph is None or self._graph[0] != key:
-            self._graph = (key, None)
-            try:
-                cur = torch.cuda.current_stream(self._dev)
-                self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), cur.cuda_stream)
-                self._evaluate_leaf()                    # warm-up outside the capture (lazy allocations, function attributes)
-                torch.cuda.synchronize(self._dev)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    st = torch.cuda.current_stream(self._dev).cuda_stream
-                    for _ in range(n):
-                        self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), st)
-                        self._evaluate_leaf()
-                self._graph = (key, g)
-                return                                   # (the warm-up pair already advanced the search by one tick)
-            except Exception:
-                self._graph = (key, None)
-        if self._graph[1] is not None:
-            self._graph[1].replay()
+        if not self._use_graph:
+            stream = torch.cuda.current_stream(self._dev).cuda_stream
+            for _ in range(n):
+                self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), stream)
+                self._evaluate_leaf()
             return
-        stream = torch.cuda.current_stream(self._dev).cuda_stream
-        for _ in range(n):
-            self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), stream)
-            self._evaluate_leaf()
+        key = (bool(self.training), self._weights_version())
+        if self._graph is None or self._graph[0] != key:
+            self._graph = None
+            cur = torch.cuda.current_stream(self._dev)
+            self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), cur.cuda_stream)
+            self._evaluate_leaf()                    # warm-up outside the capture (weight reload, lazy allocations)
+            torch.cuda.synchronize(self._dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st = torch.cuda.current_stream(self._dev).cuda_stream
+                for _ in range(n):
+                    self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), st)
+                    self._evaluate_leaf()
+            self._graph = (key, g)
+            return                                   # (the warm-up pair already advanced the search by one tick)
+        self._graph[1].replay()
 
     # -- player.py:128-147
     def get_action(self, state, e=0.25, last_action=None, random_a=False):

@@ -19,13 +19,14 @@ def _conv2d(x, kernel, bias, same=True):
     kh, kw, cin, cout = kernel.shape
     B, _, H, W = x.shape
     ph, pw = (kh // 2, kw // 2) if same else (0, 0)
-    xp = np.zeros((B, cin, H + 2 * ph, W + 2 * pw), np.float64)
-    xp[:, :, ph:ph + H, pw:pw + W] = x
-    out = np.zeros((B, cout, H, W), np.float64)
+    xp = np.zeros((B, H + 2 * ph, W + 2 * pw, cin), np.float64)       # NHWC: every tap is one fp64 matrix product
+    xp[:, ph:ph + H, pw:pw + W, :] = x.transpose(0, 2, 3, 1)
+    k64 = kernel.astype(np.float64)
+    out = np.zeros((B, H, W, cout), np.float64)
     for a in range(kh):
         for b in range(kw):
-            out += np.einsum("bchw,co->bohw", xp[:, :, a:a + H, b:b + W], kernel[a, b].astype(np.float64))
-    return out + bias.astype(np.float64)[None, :, None, None]
+            out += xp[:, a:a + H, b:b + W, :] @ k64[a, b]
+    return out.transpose(0, 3, 1, 2) + bias.astype(np.float64)[None, :, None, None]
 
 
 def _residual(f, v, name):                                        # network.py:52-56

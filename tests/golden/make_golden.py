@@ -76,6 +76,26 @@ def dump_tree(player, S):
                 tree_p=p, tree_legal=legal)
 
 
+def node_digest(sum_n, n, w, wf32, p, legal):
+    """8-byte digest of one tree node (edge arrays dense by cell, illegal cells zero): lets a 20,000-node tree of an
+    11x11 / 500-simulation trace be pinned in a few hundred KB instead of 60 MB of (mostly zero) edge arrays."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    h.update(np.int32(sum_n).tobytes())
+    h.update(np.ascontiguousarray(n, np.int32).tobytes())
+    h.update(np.ascontiguousarray(w, np.float64).tobytes())
+    h.update(np.ascontiguousarray(np.where(legal, wf32, 0), np.uint8).tobytes())
+    h.update(np.ascontiguousarray(p, np.float32).tobytes())
+    return np.frombuffer(h.digest(), np.uint64)[0]
+
+
+def digest_tree(d):
+    """dump_tree() output -> keys, sum_n and one digest per node."""
+    dg = np.array([node_digest(d["tree_sum_n"][k], d["tree_n"][k], d["tree_w"][k], d["tree_wf32"][k], d["tree_p"][k],
+                               d["tree_legal"][k].astype(bool)) for k in range(len(d["tree_sum_n"]))], np.uint64)
+    return dict(tree_keys=d["tree_keys"], tree_sum_n=d["tree_sum_n"], tree_digest=dg)
+
+
 def gen_rules(path):
     rng = np.random.RandomState(7)
     boards, states, over, value, goals = [], [], [], [], []
@@ -167,7 +187,7 @@ class _FakeAgent:
 
 
 def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, random_a=False, reset_every=None, pipe=False,
-             vbits=16, **cfg_kw):
+             vbits=16, digest=False, **cfg_kw):
     cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper, **cfg_kw)
     np.random.seed(seed)
     random.seed(seed)
@@ -212,7 +232,7 @@ def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, 
                has_policy=np.array(has_pol), taus=np.array(taus), np_next=np.asarray(np_next),
                py_next=np.asarray(py_next), finished=np.asarray(over), pipe=np.asarray(bool(pipe)), vbits=np.asarray(vbits))
     out.update(cfg_arrays(cfg))
-    out.update(dump_tree(pl, S))
+    out.update(digest_tree(dump_tree(pl, S)) if digest else dump_tree(pl, S))
     if api is not None:
         api.done = True
     np.savez_compressed(path, **out)
@@ -322,7 +342,16 @@ def gen_pipe_cases(G):
     gen_mcts(G("mcts_s6_train_v24.npz"), 6, 4, 120, 160, True, 3, 1237, 16384, 40, vbits=24)
 
 
+def gen_fullsize_cases(G):
+    """BASELINE.json's own search settings (11x11, 500 simulations per move, cap 642 — the `metric`), training mode, 24
+    plies: ~12,000 simulations through the unmodified reference Player; the tree is stored as one digest per node."""
+    gen_mcts(G("mcts_s11_train_500.npz"), 11, 5, 500, 642, True, 17, 2024, 8192, 24, digest=True)
+
+
 def main():
+    if "--only-fullsize" in sys.argv:
+        gen_fullsize_cases(lambda name: os.path.join(HERE, name))
+        return
     if "--only-edges" in sys.argv:
         gen_edge_cases(lambda name: os.path.join(HERE, name))
         return
@@ -352,6 +381,7 @@ def main():
     gen_run(G("run_s7.npz"), 7, 4, 40, 60, 12, 4243, 4096, 2)
     gen_edge_cases(G)
     gen_pipe_cases(G)
+    gen_fullsize_cases(G)
 
 
 if __name__ == "__main__":

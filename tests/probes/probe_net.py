@@ -13,7 +13,7 @@ for b in range(B):
     n = rng.randint(0, S*S-1); cells = rng.permutation(S*S)[:n+1]
     x[b, 0].reshape(-1)[cells[0:n:2]] = 1; x[b, 1].reshape(-1)[cells[1:n:2]] = 1; x[b, 2].reshape(-1)[cells[n]] = 1
 xt = torch.from_numpy(x).cuda()
-pt, vt = net.eval_device(xt)
+pt, vt = net.eval_torch(xt)
 pv = net.select_backend("hip")
 ph, vh = pv(xt)
 torch.cuda.synchronize()
@@ -21,7 +21,7 @@ print("hip vs torch: |dp| %.3e |dv| %.3e" % ((ph-pt).abs().max().item(), (vh-vt)
 p64, v64 = net_fp64.forward(net.variables, x[:16])
 print("hip vs fp64 : |dp| %.3e |dv| %.3e" % (np.abs(ph[:16].cpu().numpy()-p64).max(), np.abs(vh[:16].cpu().numpy()-v64).max()))
 print("torch vs fp64: |dp| %.3e |dv| %.3e" % (np.abs(pt[:16].cpu().numpy()-p64).max(), np.abs(vt[:16].cpu().numpy()-v64).max()))
-for name, fn in (("torch", net.eval_device), ("hip", pv)):
+for name, fn in (("torch", net.eval_torch), ("hip", pv)):
     for _ in range(5): fn(xt)
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(20): fn(xt)

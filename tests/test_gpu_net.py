@@ -36,10 +36,14 @@ def test_hip_net_matches_fp64_restatement_and_torch_reference():
     p, v = pv(xt)
     p, v = p.cpu().numpy().copy(), v.cpu().numpy().copy()
     assert p.shape == (512, 121) and v.shape == (512,)
-    p64, v64 = net_fp64.forward(net.variables, x[:96])
-    assert np.abs(v[:96] - v64).max() < 1e-5          # BASELINE.json: value within 1e-5 (fp32)
-    assert np.abs(p[:96] - p64).max() < 1e-5
-    pt, vt = net.eval_device(xt)                       # plain PyTorch fp32 reference (MIOpen picks Winograd)
+    p64, v64 = net_fp64.forward(net.variables, x)      # all 512 positions (the fp64 restatement is one dgemm per tap)
+    dv, dp = np.abs(v - v64), np.abs(p - p64)
+    print("|dv| max %.3g  |dp| max %.3g (first 96: %.3g)" % (dv.max(), dp.max(), dp[:96].max()))
+    assert dv.max() < 1e-5                             # BASELINE.json: value within 1e-5 (fp32) — on every position
+    # north_star binds the value only.  Probabilities: these random dense positions are unnatural inputs on which every fp32
+    # path (PyTorch-ROCm fp32 ops included) sits at the edge of 1e-5; measured 1.3e-5 over the 512, hence the honest bar:
+    assert dp[:96].max() < 1e-5 and dp.max() < 2e-5
+    pt, vt = net.eval_torch(xt)                        # plain PyTorch fp32 reference (MIOpen picks Winograd)
     assert (torch.from_numpy(v).cuda() - vt).abs().max().item() < 5e-5
     assert (torch.from_numpy(p).cuda() - pt).abs().max().item() < 5e-5
     assert np.allclose(p.sum(1), 1.0, atol=1e-5)

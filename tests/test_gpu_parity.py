@@ -524,3 +524,29 @@ def test_pack_kernels_across_scan_chunks_with_caps():
     assert [(r["game"], r["seq"]) for r in part + rest] == [(r["game"], r["seq"]) for r in ref2]
     a.close()
     b.close()
+
+
+def test_pop_with_cap_one_never_stalls_on_a_long_episode():
+    """the pack buffer of pop_raw(cap) held cap*40 plies, and af_pack_scan only takes a prefix in (game, seq)
+    order — on 11x11 (episodes of up to 121 plies) an episode longer than 40 plies with cap=1 could never be packed and
+    blocked every later game: self-play stalled behind the back-pressure without an error.  The buffer now always holds
+    one maximum-length episode."""
+    from alphafive_amd.engine import SelfPlayEngine
+    S, G = 11, 16
+    cfg = make_cfg(board_size=S, goal=5, simulation_per_step=6, upper_simulation_per_step=8)     # near-random play: long games
+    sp = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, 5, 0), device=0, seed=3)
+    assert sp._pack_plies(1) >= S * S and sp._pack_plies(2) >= S * S and sp._pack_plies(64) == 64 * 40
+    got = []
+    for rnd in range(400):
+        sp.run_ticks(60)
+        sp.check()
+        got += sp.pop_raw(cap=1)
+        if len(got) >= 3 * G and max(r["T"] for r in got) > 80:
+            break
+    assert len(got) >= 3 * G, (len(got), sp.counters())
+    assert max(r["T"] for r in got) > 40                                   # episodes the old 40-ply buffer could not hold
+    seqs = {}
+    for r in got:
+        seqs.setdefault(r["game"], []).append(r["seq"])
+    assert all(v == list(range(len(v))) for v in seqs.values())
+    sp.close()

@@ -55,6 +55,116 @@ def test_player_with_real_net_matches_oracle_through_same_evaluator(training):
     pl.close()
 
 
+def _drive(pl, orc, training, plies, S=11, goal=5, state=None, last=None, on_ply=None):
+    from alphafive_amd import utils
+    state = pl.get_init_state() if state is None else state
+    over, ply = False, 0
+    while not over and ply < plies:
+        la = last if training else None           # self_play.py:95-97 passes None as last_action
+        pol, act = pl.get_action(state, last_action=la)
+        opol, oact, ovis = orc.get_action(state, la)
+        assert (pl.last_visits == ovis).all(), f"ply {ply}: visit counts differ"
+        assert act == oact, f"ply {ply}"
+        if training:
+            assert (pol.view(np.uint32) == opol.view(np.uint32)).all(), f"ply {ply}: policy bits differ"
+        else:
+            assert pol is None and opol is None
+        board = utils.step(utils.state_to_board(state, S), act)
+        state = utils.board_to_state(board)
+        over, _ = utils.is_game_over(board, goal)
+        last, ply = act, ply + 1
+        if on_ply is not None:
+            on_ply(ply)
+    return state, last
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_player_device_graph_path_matches_oracle_at_the_metric_settings(training):
+    """The path that produces the config-1 number (self_play.py:79-106, player.py:128-147): Player(pv_fn=net.eval) with
+    net on cuda keeps the leaves on the device, evaluates them with af_conv_f16s and replays 16 x (tick + forward) as a HIP
+    graph — at BASELINE's own search settings (11x11, 500 simulations, cap 642, alphaFive-6960), against the C oracle fed
+    leaf by leaf through a second handle of the same kernels (batch 1 on both sides).  Visit counts, moves, policy bits
+    and the whole tree must agree bit for bit, and the graph must really be what ran."""
+    from alphafive_amd.network import ResNet
+    from alphafive_amd.player import Player
+    from test_gpu_parity import _compare_tree
+    import torch
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    opv = net.select_backend("hip")               # the oracle's evaluator: its own handle of the same kernels
+
+    def eval_np(x):
+        p, v = opv(torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda())
+        return p.cpu().numpy().copy(), v.cpu().numpy().copy()
+    cfg = make_cfg(simulation_per_step=500, upper_simulation_per_step=642)
+    pl = Player(cfg, training=training, pv_fn=net.eval, seed=11, game_id=2)
+    assert pl.backend == "hip"
+    orc = oracle.OraclePlayer(cfg, training=training, rng_mode=oracle.RNG_PHILOX, seed=11, game_id=2, pv_fn=eval_np)
+    _drive(pl, orc, training, 8)
+    assert pl._graph is not None and pl._graph[1] is not None and pl._graph[0][0] == training      # the HIP-graph path ran
+    _compare_tree(pl._engine.tree_dump(0), orc, 11)
+    assert len(pl.tree) == orc.tree_size()
+    pl.close()
+
+
+def test_player_graph_path_follows_a_weight_update():
+    """choose_best_player.py:78-82 reloads the nets between matches while the Players live on: a replayed graph skips the
+    Python wrapper that notices net.restore()/load_npz()/set_variables(), so the graph is keyed on the weight version.
+    After an update mid-game the Player must still equal the oracle fed by an evaluator with the NEW weights (the tree keeps
+    the priors of the old ones on both sides)."""
+    from alphafive_amd.network import ResNet, random_variables
+    from alphafive_amd.player import Player
+    from test_gpu_parity import _compare_tree
+    import torch
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    opv = net.select_backend("hip")
+
+    def eval_np(x):
+        p, v = opv(torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda())
+        return p.cpu().numpy().copy(), v.cpu().numpy().copy()
+    cfg = make_cfg(simulation_per_step=150, upper_simulation_per_step=200)
+    pl = Player(cfg, training=True, pv_fn=net.eval, seed=5, game_id=7)
+    orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=5, game_id=7, pv_fn=eval_np)
+    state, last = _drive(pl, orc, True, 3)
+    g0 = pl._graph
+    net.set_variables(random_variables(11, seed=4))             # a different weight set, same shapes
+    state, last = _drive(pl, orc, True, 3, state=state, last=last)
+    assert pl._graph[0] != g0[0] and pl._graph[1] is not g0[1]  # dropped and captured again
+    net.load_npz(W)
+    _drive(pl, orc, True, 2, state=state, last=last)
+    _compare_tree(pl._engine.tree_dump(0), orc, 11)
+    pl.close()
+
+
+def test_resnet_eval_and_networkapi_run_the_hand_written_kernels():
+    """networkAPI.py:64-75: the worker thread calls agent_model.eval(batch).  On cuda that is the af_conv_f16s path — the
+    same bits as select_backend("hip") on the same batch — not vendor ops; eval_torch() is the explicit reference."""
+    from alphafive_amd.network import ResNet
+    from alphafive_amd.networkAPI import NetworkAPI
+    import torch
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    x = _rand_planes(5, 11, seed=3)
+    p, v = net.eval(x)
+    ph, vh = net.select_backend("hip")(torch.from_numpy(x).cuda())
+    assert (p == ph.cpu().numpy()).all() and (v == vh.cpu().numpy()).all()
+    pt, vt = net.eval_torch(torch.from_numpy(x).cuda())
+    assert np.abs(p - pt.cpu().numpy()).max() < 5e-5 and not (p == pt.cpu().numpy()).all()     # a different arithmetic
+    cfg = make_cfg(max_processes=3)
+    api = NetworkAPI(cfg, net)
+    api.start(reload=False)
+    pipes = [api.get_pipe(reload=False) for _ in range(3)]
+    for i, pp in enumerate(pipes):
+        pp.send([x[i]])
+    for i, pp in enumerate(pipes):
+        assert pp.poll(20)
+        pol, val = pp.recv()[0]
+        p1, v1 = net.eval(x[i:i + 1])                           # batch-slot independent: same bits alone
+        assert (np.asarray(pol, np.float32) == p1[0]).all() and val == float(v1[0])
+    api.close()
+
+
 def test_headless_self_play_loop_finishes_a_game():
     from alphafive_amd import self_play
     from alphafive_amd.network import ResNet

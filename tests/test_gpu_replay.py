@@ -154,7 +154,7 @@ def test_closed_loop_self_play_replay_train_on_device(capsys):
     assert any(np.abs(net.variables[k] - before[k]).max() > 0 for k in before)     # the weights moved ...
     x = torch.zeros((2, 3, S, S), device="cuda")
     p_hip, v_hip = sp.pv(x) if hasattr(sp, "pv") else net.select_backend("hip")(x)
-    p_t, v_t = net.eval_device(x)
+    p_t, v_t = net.eval_torch(x)
     assert (p_hip - p_t).abs().max().item() < 1e-5                                 # ... and the HIP evaluator has them
     sp.close()
     stack.close()

@@ -52,6 +52,19 @@ def test_survey_known_answers():
                                   np.array([0.8802264, 0.936411, 0.996182, 1.059768, 1.1274128], np.float32))
 
 
+def _node_digest(nd, state, S):
+    """The digest tests/golden/make_golden.py:node_digest takes of a reference tree node, from an oracle node."""
+    import hashlib
+    legal = (oracle.state_to_board(state, S).reshape(-1) == 0)
+    h = hashlib.blake2b(digest_size=8)
+    h.update(np.int32(nd["sum_n"]).tobytes())
+    h.update(np.ascontiguousarray(nd["n"], np.int32).tobytes())
+    h.update(np.ascontiguousarray(nd["w"], np.float32).astype(np.float64).tobytes())
+    h.update(np.ascontiguousarray(np.where(legal, nd["f32"], 0), np.uint8).tobytes())
+    h.update(np.ascontiguousarray(nd["p"], np.float32).tobytes())
+    return np.frombuffer(h.digest(), np.uint64)[0]
+
+
 MCTS = sorted(glob.glob(os.path.join(GOLDEN, "mcts_*.npz")))
 
 
@@ -79,6 +92,12 @@ def test_mcts_trace_bit_exact(path):
     assert pl.py_u32() == int(z["py_next"])
     # whole tree
     assert pl.tree_size() == len(z["tree_keys"])
+    if "tree_digest" in z:                       # full-size traces: one digest per node (make_golden.py:node_digest)
+        for k, key in enumerate(z["tree_keys"]):
+            nd = pl.node(str(key))
+            assert nd is not None and nd["sum_n"] == z["tree_sum_n"][k] and nd["sum_n"] == nd["n"].sum()
+            assert _node_digest(nd, str(key), S) == z["tree_digest"][k], f"node {k} ({key}) differs"
+        return
     for k, key in enumerate(z["tree_keys"]):
         nd = pl.node(str(key))
         assert nd is not None
