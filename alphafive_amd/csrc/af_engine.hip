@@ -801,9 +801,21 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 for (int k = 0; k < KW; ++k) acc = k == 0 ? dd[0] : acc + dd[k];
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
-                const double inv = 1.0 / acc;
+                if (acc == 0.0) {
+                    // every variate underflowed (alpha small, few legal cells; ~2^-24 per select at alpha = 0.3 and L = 1):
+                    // 1/acc would make the priors NaN and the candidate set empty.  Spec (include/af_noise.h, the oracle does
+                    // the same): the draw degenerates to the uniform distribution over the legal cells.
+                    int cnt = 0;
 #pragma unroll
-                for (int k = 0; k < KW; ++k) dd[k] = dd[k] * inv;
+                    for (int k = 0; k < KW; ++k) cnt += __popcll(legal[k]);
+                    const double u = 1.0 / (double)cnt;
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) dd[k] = ((legal[k] >> lane) & 1ull) ? u : 0.0;
+                } else {
+                    const double inv = 1.0 / acc;
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) dd[k] = dd[k] * inv;
+                }
             }
             const double sq = sqrt((double)(sum_n + 1));
             float sc[KW];

@@ -1372,7 +1372,9 @@ int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, 
     if (!n || !planes || !policy || !value || batch < 1 || batch > n->max_batch) return AF_NET_ERR_ARG;
     if (!n->ready) return AF_NET_ERR_STATE;
     hipStream_t st = (hipStream_t)stream;
-    const int ns = g_substreams;
+    // concurrent sub-batches only on the fp32 paths (their buffers are offset by b0): the split-operand path keeps ONE set
+    // of activation buffers indexed from position 0, so chains running side by side would overwrite each other
+    const int ns = (g_wino == 5 && n->f16s != nullptr) ? 1 : g_substreams;
     if (g_seqsub > 1 && batch >= 512 * g_seqsub) {
         // sequential sub-batches on ONE stream: the split-operand path re-uses its activation buffers for every sub-batch
         // (positions are indexed from 0), so a sub-batch's producer -> consumer traffic can stay inside the Infinity Cache

@@ -217,6 +217,10 @@ AF_HD double af_gamma_lt1(double alpha, uint32_t sel, uint32_t episode, uint32_t
     }
 }
 
+/* Dirichlet(alpha * 1_L) over the legal cells = the gamma variates above divided by their sum (fp64; summation tree:
+ * oracle/af_oracle.c:afo_noise_philox_dirichlet).  If EVERY variate is 0 (fp32 underflow of exp(log(U)/alpha): small alpha,
+ * few legal cells) the draw is defined as the uniform distribution over the legal cells instead of 0/0. */
+
 /* uniform index in [0,m): multiply-shift on one word; m == 1 -> 0 */
 AF_HD uint32_t af_pick(uint32_t m, uint32_t sel, uint32_t episode, uint32_t stream,
                        uint32_t k0, uint32_t k1) {

@@ -401,6 +401,13 @@ void afo_noise_philox_dirichlet(double alpha, const uint64_t* legal_bb, int C, u
         for (int l = 0; l < 64; ++l) t[l] = s[l] + s[l ^ off];
         memcpy(s, t, sizeof(s));
     }
+    if (s[0] == 0.0) {       /* every variate underflowed: uniform over the legal cells (include/af_noise.h; same in the kernel) */
+        int cnt = 0;
+        for (int c = 0; c < C; ++c) cnt += (int)((legal_bb[c >> 6] >> (c & 63)) & 1ull);
+        const double u = 1.0 / (double)cnt;
+        for (int c = 0; c < C; ++c) d[c] = ((legal_bb[c >> 6] >> (c & 63)) & 1ull) ? u : 0.0;
+        return;
+    }
     const double inv = 1.0 / s[0];
     for (int c = 0; c < C; ++c) d[c] = g[c] * inv;
 }

@@ -290,6 +290,7 @@ def test_batched_arena_matches_per_game_oracle_players():
     (dict(board_size=6, goal=4, simulation_per_step=50, upper_simulation_per_step=70, c_puct=1.5,
           dirichlet_alpha=0.15, tau_decay_rate=0.8, init_temp=2.0), 24),
     (dict(board_size=9, goal=5, simulation_per_step=40, upper_simulation_per_step=60), 16),
+    (dict(board_size=4, goal=3, simulation_per_step=24, upper_simulation_per_step=30, dirichlet_alpha=0.002), 24),   # all-zero gamma draws
 ])
 def test_selfplay_edge_cases_match_oracle(kw, G):
     """Same edge cases as the tier-A goldens (run_s3_draws, run_s4_lowtau, mcts_s5_cap, mcts_s6_params):

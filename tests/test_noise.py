@@ -91,6 +91,24 @@ def test_philox_dirichlet_distribution():
     assert 0.8 * expect < var < 1.2 * expect
 
 
+def test_philox_dirichlet_degenerates_to_uniform_when_every_variate_underflows():
+    """the fp32 gamma sampler flushes X = exp(log(U)/alpha) to 0 for small alpha; with few legal cells all
+    variates can be 0 and 1/sum made the priors NaN.  Spec: uniform over the legal cells (kernel and oracle alike)."""
+    Cc = 9
+    d = np.zeros(Cc)
+    hits = 0
+    for L_cells in ([4], [0, 8], [1, 2, 5]):
+        legal = np.zeros(4, np.uint64)
+        for c in L_cells:
+            legal[c >> 6] |= np.uint64(1) << np.uint64(c & 63)
+        for sel in range(200):
+            oracle.lib().afo_noise_philox_dirichlet(0.002, legal.ctypes.data_as(C.POINTER(C.c_uint64)), Cc, sel, 1, 5, 6,
+                                                    d.ctypes.data_as(C.POINTER(C.c_double)))
+            assert np.isfinite(d).all() and abs(d.sum() - 1.0) < 1e-12 and (d[[c for c in range(Cc) if c not in L_cells]] == 0).all()
+            hits += all(d[c] == 1.0 / len(L_cells) for c in L_cells) and len(L_cells) > 1
+    assert hits > 0                              # the degenerate branch was really taken
+
+
 def test_mt_restatement_matches_numpy_and_python():
     import random
     for seed in (0, 1, 12345, 2 ** 31 + 7):
