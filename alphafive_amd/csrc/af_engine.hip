@@ -1229,6 +1229,13 @@ int af_engine_set_training(af_engine* e, int32_t training) {
     return AF_OK;
 }
 
+int af_engine_set_simulations(af_engine* e, int32_t sims, int32_t upper) {
+    if (!e || sims < 1 || upper < 1 || sims + 8 > e->P.node_cap) return AF_ERR_ARG;
+    e->P.sims = sims;
+    e->P.upper = upper;
+    return AF_OK;
+}
+
 int af_engine_set_root(af_engine* e, int32_t game, const uint64_t* key, int32_t last_cell, int32_t random_a,
                        int32_t reset_tree) {
     if (!e || !key || game < 0 || game >= e->P.G || e->P.mode != AF_MODE_EXTERNAL) return AF_ERR_ARG;

@@ -67,6 +67,7 @@ def lib():
         L.af_engine_set_root.argtypes = [vp, C.c_int32, u64p, C.c_int32, C.c_int32, C.c_int32]
         L.af_engine_move_result.argtypes = [vp, C.c_int32, i32p, i32p, f32p, i32p, C.POINTER(C.c_double)]
         L.af_engine_set_training.argtypes = [vp, C.c_int32]
+        L.af_engine_set_simulations.argtypes = [vp, C.c_int32, C.c_int32]
         L.af_engine_set_roots.argtypes = [vp, vp, C.c_int32, i32p, u64p, i32p, i32p, i32p]
         L.af_engine_move_results.argtypes = [vp, vp, C.c_int32, i32p, i32p, i32p, f32p, i32p, C.POINTER(C.c_double)]
         L.af_engine_pop_episodes.argtypes = [vp, vp, C.c_int32, i32p, f32p, u64p, f32p, i32p, i32p, i32p]
@@ -157,6 +158,10 @@ class Engine:
 
     def set_training(self, training):
         _check(lib().af_engine_set_training(self._h, int(training)), "af_engine_set_training")
+
+    def set_simulations(self, sims, upper):
+        """Budget of the moves that start from now on (the reference reads config.simulation_per_step at every get_action)."""
+        _check(lib().af_engine_set_simulations(self._h, int(sims), int(upper)), "af_engine_set_simulations")
 
     def set_root(self, game, key, last_cell=-1, random_a=False, reset_tree=False):
         key = np.ascontiguousarray(key, np.uint64)

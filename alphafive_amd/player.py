@@ -241,6 +241,8 @@ class Player(object):
         key = _eng.state_to_key(state, S)
         last_cell = -1 if last_action is None else last_action[0] * S + last_action[1]
         self._engine.set_training(self.training)
+        # player.py:140-143 reads the budget from the live config object at every call
+        self._engine.set_simulations(self.config.simulation_per_step, self.config.upper_simulation_per_step)
         self._engine.set_root(0, key, last_cell, random_a, reset_tree=self._reset_pending)
         self._reset_pending = False
         if getattr(self, "_adopt", None) is not None:          # reset(search_tree): the adopted tree replaces the fresh store

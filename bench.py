@@ -232,6 +232,52 @@ def live_net_traffic(G, ticks=400, last=200, timeout_s=180):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+EXTRA_LEGS = {
+    # BASELINE.json configs[3]: 15x15, 800 sims/move (cap 942 = the reference's 642 - 500 head-room), 4096 games
+    "config4": ["--board", "15", "--sims", "800", "--upper", "942", "--games", "4096", "--age-plies", "24", "--warmup", "3", "--steps", "6"],
+    # BASELINE.json configs[4]: 11x11, 8-block x 128 residual net in bf16, 8192 games
+    "config5": ["--net", "deep-bf16", "--games", "8192", "--age-plies", "12", "--warmup", "3", "--steps", "8"],
+}
+
+
+def extra_config_legs(timeout_s=240):
+    """Short steady-state legs of the two other single-GPU configurations BASELINE.json names, run as child processes of this
+    same file after the default workload (so the driver's one `python bench.py` sees them): flat keys configN_* on the JSON
+    line plus the children's own lines under "extra_configs".  A leg that fails or times out is reported as an error string."""
+    import subprocess
+    flat, full = {}, {}
+    for name, leg in EXTRA_LEGS.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-pmc", "--no-extra-configs"] + leg
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s,
+                               env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+            line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                flat[name + "_error"] = "rc %d: %s" % (r.returncode, r.stderr.decode()[-300:])
+                continue
+            j = json.loads(line[-1])
+        except subprocess.TimeoutExpired:
+            flat[name + "_error"] = "timed out after %d s" % timeout_s
+            continue
+        rf = j["roofline"]
+        if j["value"] is None:                      # no episode finished inside the leg: say so instead of quoting it as the metric
+            flat[name + "_steady_state"] = False
+            j["value"] = j.get("opening_phase_moves_per_s")
+        flat.update({name + "_moves_per_s": j["value"], name + "_net_ms": rf["ms_per_launch"],
+                     name + "_tick_ms": j["tree_roofline"]["ms_per_launch"], name + "_mfma_frac": rf["frac"],
+                     name + "_net_tflops": rf["achieved"], name + "_mfma_peak_tflops": rf["peak"],
+                     name + "_episodes_finished": j["config"]["episodes_finished_in_timed_region"],
+                     name + "_steps": j["steps"], name + "_ms_per_step": j["ms_per_step"], name + "_wall_s": time.time() - t0})
+        if "mfma_issued_frac" in rf:
+            flat[name + "_mfma_issued_frac"] = rf["mfma_issued_frac"]
+        full[name] = {"cmd": " ".join(["python", "bench.py"] + cmd[2:]), "metric": j["metric"], "value": j["value"], "dtype": j["dtype"],
+                      "config": j["config"], "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "ms_per_launch")},
+                      "time_split": j["time_split"]}
+    flat["extra_configs"] = full
+    return flat
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -246,6 +292,14 @@ def main():
     ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic from profiles/ instead of two rocprofv3 counter passes in this run")
+    ap.add_argument("--age-plies", type=int, default=0,
+                    help="before the warm-up steps, age the games this many plies at --age-sims simulations per move (untimed): the "
+                         "games desynchronise and reach the mixed-phase population of the steady state ~40x faster than full-budget "
+                         "plies would; the warm-up steps then rebuild full-budget trees.  Used by the short extra-config legs.")
+    ap.add_argument("--age-sims", type=int, default=16)
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short steady-state legs of BASELINE configs[3] (15x15, 800 sims) and configs[4] (8-block bf16 net, "
+                         "8192 games) that the default N=1 run appends as flat keys config4_* / config5_*")
     ap.add_argument("--pipe-values", action="store_true",
                     help="W / Q in fp64: the arithmetic of main.py's pipe-fed workers (networkAPI.py:72); default = the pv_fn path")
     ap.add_argument("--net", default="hip", choices=["hip", "torch", "deep-bf16", "deep-bf16-torch"],
@@ -362,6 +416,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     target = 0
+    if args.age_plies > 0:
+        sp.engine.set_simulations(args.age_sims, args.age_sims + 8)
+        for _ in range(args.age_plies):
+            target += G
+            run_step(target)
+        sp.engine.set_simulations(args.sims, args.upper)
     for _ in range(args.warmup):
         target += G
         run_step(target)
@@ -498,8 +558,19 @@ def main():
                 cb.update({"all_cores_value": ac["value"], "all_cores_cores": ac["cores"], "all_cores_host_cores": ac["host_cores"],
                            "all_cores_sample": ac["sample"]})
             out["cpu_baseline"] = cb
+        if args.age_plies > 0:
+            out["config"]["aged"] = ("games aged %d plies at %d sims/move before the %d full-budget warm-up steps (untimed)"
+                                     % (args.age_plies, args.age_sims, args.warmup))
+        default_workload = (world == 1 and deep is None and cfg.board_size == 11 and G == 4096 and args.sims == 500
+                            and not args.pipe_values and args.net == "hip")
+        if default_workload and not args.no_extra_configs:
+            sp.close()
+            sp = None
+            torch.cuda.empty_cache()
+            out.update(extra_config_legs())
         print(json.dumps(out), flush=True)
-    sp.close()
+    if sp is not None:
+        sp.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

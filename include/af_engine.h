@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 2
+#define AF_ABI_VERSION 3
 
 /* engine modes */
 #define AF_MODE_SELFPLAY 0   /* Player.run loop on device: games restart forever (main.py:82 gen_data) */
@@ -114,6 +114,11 @@ int af_engine_set_root(af_engine* e, int32_t game, const uint64_t* key, int32_t 
 int af_engine_move_result(af_engine* e, int32_t game, int32_t* action_cell, int32_t* has_policy, float* policy,
                           int32_t* visits, double* tau);
 int af_engine_set_training(af_engine* e, int32_t training);
+/* Simulation budget of the moves that START after this call (player.py:140-143 reads config.simulation_per_step /
+ * upper_simulation_per_step from the live config object at every get_action; the engine snapshots them at create).
+ * A move in progress keeps the budget it started with.  AF_ERR_ARG unless 1 <= sims, 1 <= upper and sims + 8 <= the
+ * node capacity chosen at create (the store collector's head-room). */
+int af_engine_set_simulations(af_engine* e, int32_t simulation_per_step, int32_t upper_simulation_per_step);
 
 /* The same for n games at once (batched arena, choose_best_player.py:38-60): one upload + one launch / one launch + one
  * download on `stream` instead of a device synchronisation and ~10 small copies per game.  keys [n][2KW]; random_a and

@@ -61,6 +61,7 @@ def lib():
         L.afo_destroy.argtypes = [vp]
         L.afo_reset.argtypes = [vp]
         L.afo_set_training.argtypes = [vp, C.c_int]
+        L.afo_set_simulations.argtypes = [vp, C.c_int, C.c_int]
         L.afo_set_value_f64.argtypes = [vp, C.c_int]
         L.afo_node_get_w64.argtypes = [vp, C.c_char_p, f64p]
         L.afo_tree_dump_w64.argtypes = [vp, C.c_int, f64p]
@@ -219,6 +220,9 @@ class OraclePlayer:
 
     def set_training(self, t):
         lib().afo_set_training(self.h, int(t))
+
+    def set_simulations(self, sims, upper):
+        lib().afo_set_simulations(self.h, int(sims), int(upper))
 
     @property
     def tau(self):

@@ -373,6 +373,8 @@ void afo_reset(afo_player* P) {
     P->episode += 1; P->sel_ctr = 0; P->ply_ctr = 0;
 }
 void afo_set_training(afo_player* P, int training) { P->training = training; }
+/* player.py:140-143 reads config.simulation_per_step / upper_simulation_per_step from the live config at every get_action */
+void afo_set_simulations(afo_player* P, int sims, int upper) { P->cfg.sims = sims; P->cfg.upper_sims = upper; }
 void afo_set_value_f64(afo_player* P, int on) { P->value_f64 = on ? 1 : 0; }
 double afo_tau(const afo_player* P) { return P->tau; }
 

@@ -68,6 +68,7 @@ afo_player* afo_create(const afo_config* cfg, int training, int rng_mode, uint64
 void afo_destroy(afo_player* p);
 void afo_reset(afo_player* p);                         /* player.py:48 */
 void afo_set_training(afo_player* p, int training);
+void afo_set_simulations(afo_player* p, int sims, int upper);
 /* 1 = the reference's pipe path: leaf values arrive as python floats (networkAPI.py:72), so w and q are fp64 (SURVEY 8a rule 2) */
 void afo_set_value_f64(afo_player* p, int on);
 int  afo_node_get_w64(const afo_player* p, const char* state, double* w);

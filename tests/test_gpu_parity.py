@@ -551,3 +551,30 @@ def test_pop_with_cap_one_never_stalls_on_a_long_episode():
         seqs.setdefault(r["game"], []).append(r["seq"])
     assert all(v == list(range(len(v))) for v in seqs.values())
     sp.close()
+
+
+def test_simulation_budget_follows_the_live_config():
+    """player.py:140-143 reads config.simulation_per_step / upper_simulation_per_step at every get_action: changing them
+    between two moves changes the next move's budget (af_engine_set_simulations; a move in progress keeps its own)."""
+    from alphafive_amd.player import Player
+    from alphafive_amd import engine as eng, utils
+    S = 7
+    cfg = make_cfg(board_size=S, goal=4, simulation_per_step=90, upper_simulation_per_step=120)
+    salt, peak = 31, 4096
+    pl = Player(cfg, training=True, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak), seed=2, game_id=5)
+    orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=2, game_id=5, pseudo_salt=salt, pseudo_peak=peak)
+    state, last = pl.get_init_state(), None
+    for sims, upper in ((90, 120), (20, 30), (150, 400), (40, 41), (90, 120)):
+        cfg.simulation_per_step, cfg.upper_simulation_per_step = sims, upper
+        orc.set_simulations(sims, upper)
+        pol, act = pl.get_action(state, last_action=last)
+        opol, oact, ovis = orc.get_action(state, last)
+        assert (pl.last_visits == ovis).all() and act == oact and (pol.view(np.uint32) == opol.view(np.uint32)).all()
+        board = utils.step(utils.state_to_board(state, S), act)
+        state, last = utils.board_to_state(board), act
+    _compare_tree(pl._engine.tree_dump(0), orc, S)
+    with pytest.raises(eng.EngineError):
+        pl._engine.set_simulations(0, 10)
+    with pytest.raises(eng.EngineError):
+        pl._engine.set_simulations(10 ** 6, 10 ** 6)          # beyond the node capacity chosen at create
+    pl.close()
