@@ -2,10 +2,13 @@
 collective on the tick path).  The only exchanges are the ones SURVEY §8e lists:
 
   broadcast_weights   one broadcast of the 3 MB fp32 weight set from rank 0 (per weight update)
-  gather_packed       finished episodes -> rank 0: the engine packs them on the device into one
-                      int32 buffer (af_engine_pack_episodes); sizes all-gather, then one padded
-                      all-gather of the used prefixes; rank 0 keeps the result — the device-side
-                      replacement of main.py:51,94's multiprocessing.Queue hand-off
+  EpisodeGather       finished episodes -> rank 0 ONLY (main.py:51,94's Queue hand-off on the device):
+                      the engine packs them into one int32 device buffer (af_engine_pack_episodes); the used
+                      sizes travel as a tiny all-gather issued with the pack and are read one step later, then
+                      one gather (grouped send/recv towards rank 0) of the used prefixes; rank 0 copies the
+                      payload to pinned host memory asynchronously and unpacks it another step later.  Nothing
+                      on the step path waits for the device (no .item()/.cpu() of fresh data).
+  gather_packed       the blocking form of the same gather (tests, one-off callers)
   gather_episodes     the same for callers that hold episode dicts
   all_reduce_sum      the moves counter for the metric
 
@@ -18,23 +21,25 @@ import torch.distributed as dist
 from .engine import packed_used_ints, unpack_episodes as _unpack_packed
 
 
-def pack_episodes(eps):
+def pack_episodes(eps, max_eps=None):
     """Host-side builder of the engine's packed hand-off layout (include/af_engine.h af_engine_pack_episodes) with
-    max_episodes = len(eps): list of raw episode dicts -> int32 numpy buffer.  (The device produces this layout itself;
-    this builder serves callers that hold episode dicts, e.g. the CPU tests.)"""
+    max_episodes = max_eps (default len(eps)): list of raw episode dicts -> int32 numpy buffer.  (The device produces this
+    layout itself; this builder serves callers that hold episode dicts, e.g. the CPU tests.)"""
     n = len(eps)
+    M = n if max_eps is None else int(max_eps)
+    assert n <= M
     K = int(eps[0]["keys"].shape[1]) if n else 4
     Cc = int(eps[0]["policies"].shape[1]) if n else 0
     R = 2 * K + 2 * Cc + 2
     plies = sum(int(e["T"]) for e in eps)
-    buf = np.zeros(4 + 5 * n + plies * R, np.int32)
+    buf = np.zeros(4 + 5 * M + plies * R, np.int32)
     buf[:4] = (n, plies, K, Cc)
     p0 = 0
     for i, e in enumerate(eps):
         T = int(e["T"])
         buf[4 + 4 * i:8 + 4 * i] = (e["game"], e["seq"], T, p0)
-        buf[4 + 4 * n + i] = np.float32(e["final_value"]).view(np.int32)
-        rec = buf[4 + 5 * n + p0 * R:4 + 5 * n + (p0 + T) * R].reshape(T, R)
+        buf[4 + 4 * M + i] = np.float32(e["final_value"]).view(np.int32)
+        rec = buf[4 + 5 * M + p0 * R:4 + 5 * M + (p0 + T) * R].reshape(T, R)
         rec[:, :2 * K] = np.ascontiguousarray(e["keys"], np.uint64).view(np.int32).reshape(T, 2 * K)
         rec[:, 2 * K:2 * K + Cc] = np.ascontiguousarray(e["policies"], np.float32).view(np.int32)
         rec[:, 2 * K + Cc:2 * K + 2 * Cc] = e["visits"]
@@ -49,38 +54,131 @@ def unpack_episodes(buf, max_eps=None):
     return _unpack_packed(buf, int(buf[0]) if max_eps is None else max_eps)
 
 
+def _localise(b, max_eps, r, games_per_rank):
+    eps = _unpack_packed(b, max_eps)
+    if games_per_rank:
+        for e in eps:
+            e["game"] += r * games_per_rank
+    return eps
+
+
+def _run_collectives(world):
+    """Collectives run whenever a process group is up — also at world size 1 (the RCCL smoke test on a 1-GPU box)."""
+    return dist.is_available() and dist.is_initialized() and (world > 1 or dist.get_world_size() == 1)
+
+
+class EpisodeGather(object):
+    """Pipelined gather of packed episode buffers to rank 0.  Per step, in this order on every rank:
+
+        eps = g.collect()                      # advances the buffers posted earlier; rank 0 gets finished payloads
+        buf = sp.post_episodes_device(cap)     # this step's pack kernels (they overwrite the engine's pack buffer)
+        g.post(buf)                            # sizes all-gather on the device, read back asynchronously
+        ...
+        eps += g.flush()                       # at the end: drains everything (blocking)
+
+    collect() must come before the next pack: the gather it issues reads the previously posted buffer.
+    max_eps / rec_ints describe the pack layout (af_engine_pack_episodes: used = 4 + 5*max_eps + plies*rec_ints).
+    `device`: where the collectives run — the GPU for "nccl" (= RCCL over xGMI), cpu for "gloo"."""
+
+    def __init__(self, world, rank, device, max_eps, rec_ints, games_per_rank=0):
+        self.world, self.rank, self.device = world, rank, torch.device(device)
+        self.max_eps, self.rec_ints, self.games_per_rank = max_eps, rec_ints, games_per_rank
+        self.collective = world > 1 or _run_collectives(world)
+        self._tickets = []
+        self.bytes_received = 0           # rank 0: payload bytes that crossed the fabric towards it
+
+    def _pinned(self, n, dtype):
+        return torch.empty(n, dtype=dtype, pin_memory=torch.cuda.is_available())
+
+    def post(self, buf):
+        """buf: the packed int32 buffer of this step (device tensor).  Issues the sizes exchange; returns at once."""
+        used = (buf[1:2].to(torch.int64) * self.rec_ints + (4 + 5 * self.max_eps))          # stays on the device
+        if self.collective:
+            allsz = torch.empty(self.world, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(allsz, used.to(self.device))
+        else:
+            allsz = used
+        if allsz.device.type == "cuda":
+            host = self._pinned(self.world, torch.int64)
+            host.copy_(allsz, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(allsz.device))
+        else:
+            host, ev = allsz.clone(), None
+        self._tickets.append({"stage": 0, "buf": buf, "sizes": host, "ev": ev})
+
+    def _gather(self, t):
+        if t["ev"] is not None:
+            t["ev"].synchronize()                 # recorded a whole step ago
+        sizes = [int(x) for x in t["sizes"].tolist()]
+        width = max(sizes)
+        payload = t["buf"][:width]
+        if payload.device != self.device:
+            payload = payload.to(self.device)
+        if payload.numel() < width:               # a caller-built buffer smaller than the widest payload (gather_episodes)
+            payload = torch.cat([payload, torch.zeros(width - payload.numel(), dtype=torch.int32, device=self.device)])
+        if self.collective:
+            dst = [torch.empty(width, dtype=torch.int32, device=self.device) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(payload.contiguous(), dst, dst=0)          # grouped send/recv towards rank 0: no other rank receives
+        else:
+            dst = [payload]
+        t.update(stage=1, buf=None, sizes=sizes)
+        if self.rank != 0:
+            t["stage"] = 2
+            t["host"] = None
+            return
+        self.bytes_received += sum(sizes[1:]) * 4
+        hosts, ev = [], None
+        for r in range(self.world):
+            src = dst[r][:sizes[r]]
+            if src.device.type == "cuda":
+                h = self._pinned(sizes[r], torch.int32)
+                h.copy_(src, non_blocking=True)
+                hosts.append(h)
+            else:
+                hosts.append(src.clone())
+        if self.device.type == "cuda" or t.get("ev") is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        t["host"], t["ev"] = hosts, ev
+
+    def _unpack(self, t):
+        if t["host"] is None:
+            return []
+        if t["ev"] is not None:
+            t["ev"].synchronize()
+        out = []
+        for r, h in enumerate(t["host"]):
+            out += _localise(h.numpy(), self.max_eps, r, self.games_per_rank)
+        return out
+
+    def collect(self, drain=False):
+        """Advance every posted buffer by one stage (all of them to the end with drain=True); -> rank 0: the episodes
+        whose payload has arrived, other ranks: []."""
+        out, keep = [], []
+        for t in self._tickets:
+            if t["stage"] == 0:
+                self._gather(t)
+                if not drain:
+                    keep.append(t)
+                    continue
+            out += self._unpack(t)
+        self._tickets = keep
+        return out
+
+    def flush(self):
+        return self.collect(drain=True)
+
+
 def gather_packed(buf, max_eps, world, rank, device, games_per_rank=0):
-    """buf: this rank's packed hand-off buffer (torch int32, device or host; layout of af_engine_pack_episodes with
-    the given max_eps).  Rank 0 gets every rank's episodes (game ids made global: + r * games_per_rank), the other
-    ranks get [].  One sizes all-gather and one padded all-gather of the used prefixes (RCCL over xGMI on GPUs:
-    the packed device buffer goes to the collective as it is, no host round trip on the sending side)."""
+    """Blocking form: buf = this rank's packed hand-off buffer (torch int32, device or host; layout of
+    af_engine_pack_episodes with the given max_eps).  Rank 0 gets every rank's episodes (game ids made global:
+    + r * games_per_rank), the other ranks get [].  One sizes all-gather, one gather of the used prefixes to rank 0."""
     hdr = buf[:4].cpu().numpy()                       # waits for the pack kernels of this buffer only
-    used = packed_used_ints(hdr, max_eps)
-
-    def local(b, r):
-        eps = _unpack_packed(b, max_eps)
-        if games_per_rank:
-            for e in eps:
-                e["game"] += r * games_per_rank
-        return eps
-
-    if world == 1:
-        return local(buf[:used].cpu().numpy(), 0)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([used], dtype=torch.int64, device=device))
-    sizes = [int(s.item()) for s in sizes]
-    width = max(sizes)
-    payload = buf[:width].to(device)
-    if payload.numel() < width:                       # a rank whose buffer is smaller than the widest payload
-        payload = torch.cat([payload, torch.zeros(width - payload.numel(), dtype=torch.int32, device=device)])
-    bufs = [torch.empty(width, dtype=torch.int32, device=device) for _ in range(world)]
-    dist.all_gather(bufs, payload.contiguous())
-    if rank != 0:
-        return []
-    out = []
-    for r in range(world):
-        out += local(bufs[r][:sizes[r]].cpu().numpy(), r)
-    return out
+    rec = 2 * int(hdr[2]) + 2 * int(hdr[3]) + 2
+    g = EpisodeGather(world, rank, device, max_eps, rec, games_per_rank)
+    g.post(buf)
+    return g.flush()
 
 
 def gather_episodes(eps, world, rank, device, game_offset=None):
@@ -94,27 +192,23 @@ def gather_episodes(eps, world, rank, device, game_offset=None):
     n = torch.tensor([len(eps)], dtype=torch.int64, device=device)
     dist.all_reduce(n, op=dist.ReduceOp.MAX)
     max_eps = int(n.item())
-    own = pack_episodes(eps)
-    # re-home the ply region to the common max_eps
-    k = len(eps)
-    buf = np.zeros(4 + 5 * max_eps + (own.size - 4 - 5 * k), np.int32)
-    buf[:4] = own[:4]
-    buf[4:4 + 4 * k] = own[4:4 + 4 * k]
-    buf[4 + 4 * max_eps:4 + 4 * max_eps + k] = own[4 + 4 * k:4 + 5 * k]
-    buf[4 + 5 * max_eps:] = own[4 + 5 * k:]
-    if k == 0:
-        buf[2], buf[3] = 0, 0
+    buf = pack_episodes(eps, max_eps)
     return gather_packed(torch.from_numpy(buf), max_eps, world, rank, device)
 
 
 def broadcast_weights(net, src=0):
-    """Replicate rank `src`'s network variables on every rank (ncclBroadcast per tensor)."""
+    """Replicate rank `src`'s network variables on every rank: ONE broadcast of the flattened weight set (3 MB at 11x11;
+    main.py:73-75 hands new weights to its workers through a checkpoint file)."""
     dev = net.device if (net.device.type == "cuda" and dist.get_backend() == "nccl") else torch.device("cpu")
-    new = {}
-    for name in sorted(net.variables):
-        t = torch.from_numpy(net.variables[name]).to(dev)
-        dist.broadcast(t, src=src)
-        new[name] = t.cpu().numpy()
+    names = sorted(net.variables)
+    flat = torch.from_numpy(np.concatenate([np.ascontiguousarray(net.variables[k], np.float32).reshape(-1) for k in names])).to(dev)
+    dist.broadcast(flat, src=src)
+    flat = flat.cpu().numpy()
+    new, at = {}, 0
+    for k in names:
+        n = net.variables[k].size
+        new[k] = flat[at:at + n].reshape(net.variables[k].shape).copy()
+        at += n
     net.set_variables(new)
 
 

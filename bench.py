@@ -376,6 +376,8 @@ def main():
         else:
             sp.tick()
 
+    EP_CAP = 512                                      # episodes per hand-off (~G/26 finish per step; the rest waits)
+
     def run_step(target):
         while True:
             for _ in range(args.poll):
@@ -386,28 +388,35 @@ def main():
         sp.check()
         hand_off()
 
-    EP_CAP = 512                                      # episodes per hand-off (~G/26 finish per step; the rest waits)
     posted = {"buf": None}
 
-    def collect():
-        # finished episodes -> rank 0.  N = 1: the pack kernels wrote them into pinned host memory; N > 1: the packed
-        # device buffer goes through one RCCL all-gather over xGMI (alphafive_amd.dist.gather_packed).
-        if posted["buf"] is None:
-            return
+    gat = None
+    if world > 1:
+        # finished episodes -> rank 0 only: sizes ride a tiny all-gather issued with the pack, the used prefixes follow one step
+        # later as ONE gather towards rank 0 (RCCL grouped send/recv over xGMI); nothing here waits for the device
+        gat = afdist.EpisodeGather(world, rank, comm_dev, EP_CAP, 2 * sp.engine.KW2 + 2 * C + 2, games_per_rank=G)
+
+    def collect(last=False):
+        # N = 1: the pack kernels wrote the episodes into pinned host memory one step ago
         if world == 1:
+            if posted["buf"] is None:
+                return
             eps = sp.collect_episodes(EP_CAP)
+            posted["buf"] = None
         else:
-            eps = afdist.gather_packed(posted["buf"], EP_CAP, world, rank, comm_dev, games_per_rank=G)
-        posted["buf"] = None
+            eps = gat.flush() if last else gat.collect()
         if rank == 0:
             gathered["episodes"] += len(eps)
             gathered["plies"] += sum(e["T"] for e in eps)
 
     def hand_off():
-        # collect what was posted one step ago (its kernels retired long ago: nothing waits), then post this step's
+        # collect what was posted earlier (its kernels retired long ago: nothing waits), then post this step's
         # episodes behind the ticks already queued — the hand-off never sits on the tick path
         collect()
-        posted["buf"] = sp.post_episodes(EP_CAP) if world == 1 else sp.post_episodes_device(EP_CAP)
+        if world == 1:
+            posted["buf"] = sp.post_episodes(EP_CAP)
+        else:
+            gat.post(sp.post_episodes_device(EP_CAP))
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -434,7 +443,7 @@ def main():
     for _ in range(args.steps):
         target += G
         run_step(target)
-    collect()                                         # the last step's episodes
+    collect(last=True)                                # the last steps' episodes
     barrier()
     elapsed = time.perf_counter() - t0
     timing["on"] = False

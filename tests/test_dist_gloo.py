@@ -30,8 +30,20 @@ def _worker(rank, world, port, q):
     net = ResNet(6, device="cpu", seed=rank)          # different weights per rank before the broadcast
     afdist.broadcast_weights(net, src=0)
     digest = float(sum(np.abs(v).sum() for v in net.variables.values()))
+    # the pipelined form bench.py uses: collect -> pack -> post per step, flush at the end; payloads lag two steps
+    M, R = 6, 2 * 4 + 2 * 36 + 2
+    g = afdist.EpisodeGather(world, rank, dev, M, R, games_per_rank=1000)
+    piped, lag = [], []
+    for step in range(5):
+        got_now = g.collect()
+        lag.append(len(got_now))
+        piped += got_now
+        mine_s = [_episode(rank, 10 * step + i, 4 + i + step) for i in range((step + rank) % 4)]      # ragged, sometimes empty
+        g.post(torch.from_numpy(afdist.pack_episodes(mine_s, M)))
+    piped += g.flush()
     q.put((rank, [(e["game"], e["seq"], e["T"], e["final_value"], float(e["policies"].sum()),
-                   int(e["visits"].sum()), int(e["keys"].sum() % 1000003)) for e in got], total, digest))
+                   int(e["visits"].sum()), int(e["keys"].sum() % 1000003)) for e in got], total, digest,
+           [(e["game"], e["T"], int(e["visits"].sum())) for e in piped], lag, g.bytes_received))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,6 +72,15 @@ def test_world2_gather_broadcast_allreduce():
     assert res[1][1] == []
     assert res[0][2] == res[1][2] == sum(t[2] for t in expect)
     assert res[0][3] == res[1][3]                       # identical weights after the broadcast
+    want = []
+    for step in range(5):                               # pipelined gather: everything arrives at rank 0, in (step, rank) order
+        for rank in range(2):
+            for i in range((step + rank) % 4):
+                e = _episode(rank, 10 * step + i, 4 + i + step)
+                want.append((e["game"] + rank * 1000, e["T"], int(e["visits"].sum())))
+    assert res[0][4] == want and res[1][4] == []
+    assert res[0][5][:2] == [0, 0]                      # nothing can arrive before two steps have passed (sizes, then payload)
+    assert res[0][6] > 0 and res[1][6] == 0             # only rank 0 receives payload bytes
 
 
 def test_pack_unpack_roundtrip_empty_and_ragged():
