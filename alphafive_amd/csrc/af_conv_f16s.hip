@@ -57,11 +57,57 @@ constexpr uint32_t kZoff = kLds0 + kRing * kSlabB; // all-zero region (edge lane
 constexpr uint32_t kBiasOff = kZoff + kSlabB;   // 128 floats
 constexpr uint32_t kScrOff = kBiasOff + 512u;   // k-split exchange
 
+// Build-time variants (A/B'ed by tools/probe_f16s_ab.py; the defaults are what measured best):
+//   AF_F16S_STW       1: the epilogue's stores stay in flight across the next position's first LDS-DMA waits (see "stores in flight")
+//   AF_F16S_NT_STORE  1: the activation stores carry the nt (streaming) hint
+//   AF_F16S_NT_LOAD   1: the LDS-DMA slab loads carry the nt hint
+#ifndef AF_F16S_STW
+#define AF_F16S_STW 1
+#endif
+#ifndef AF_F16S_NT_STORE
+#define AF_F16S_NT_STORE 0
+#endif
+#ifndef AF_F16S_NT_LOAD
+#define AF_F16S_NT_LOAD 0
+#endif
+
+// 16-byte store issued by hand: exactly one vmcnt-counted instruction, invisible to the compiler's own wait-count bookkeeping
+// (which is what lets the kernel count it in its s_waitcnt immediates)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16(void* gdst, const h8& v) {
+    u32x4 r;
+    __builtin_memcpy(&r, &v, 16);
+#if AF_F16S_NT_STORE
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(gdst), "v"(r) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(gdst), "v"(r) : "memory");
+#endif
+}
+
+// s_waitcnt vmcnt(n) for an n that is a constant once the surrounding loops are unrolled (the immediate is part of the instruction)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define AF_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        AF_VM(0) AF_VM(1) AF_VM(2) AF_VM(3) AF_VM(4) AF_VM(5) AF_VM(6) AF_VM(7) AF_VM(8) AF_VM(9) AF_VM(10) AF_VM(11) AF_VM(12) AF_VM(13)
+        AF_VM(14) AF_VM(15) AF_VM(16) AF_VM(17) AF_VM(18) AF_VM(19) AF_VM(20) AF_VM(21) AF_VM(22) AF_VM(23) AF_VM(24) AF_VM(25) AF_VM(26)
+        AF_VM(27) AF_VM(28) AF_VM(29) AF_VM(30) AF_VM(31) AF_VM(32) AF_VM(33) AF_VM(34) AF_VM(35) AF_VM(36) AF_VM(37) AF_VM(38) AF_VM(39)
+        AF_VM(40) AF_VM(41) AF_VM(42) AF_VM(43) AF_VM(44) AF_VM(45) AF_VM(46) AF_VM(47) AF_VM(48) AF_VM(49) AF_VM(50) AF_VM(51) AF_VM(52)
+        AF_VM(53) AF_VM(54) AF_VM(55) AF_VM(56) AF_VM(57) AF_VM(58) AF_VM(59) AF_VM(60) AF_VM(61) AF_VM(62) AF_VM(63)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef AF_VM
+}
+
 // LDS-DMA: 16 bytes per lane from global memory into LDS at (wave-uniform lds_dst) + lane*16; counted on vmcnt.
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     unsigned keep;
+#if AF_F16S_NT_LOAD
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
@@ -77,6 +123,14 @@ __device__ unsigned long long g_f16s_cycles[10][512][4][9];
 #define AF_T(var)
 #define AF_TACC(slot, a, b)
 #endif
+
+// epilogues (one after the last slab of every position) that lie between the request of slab t+1 — made during slab
+// t+1-kDist — and the barrier inside slab t, for slab j = t mod SPP of a position
+constexpr int epilogues_in_window(int j, int SPP) {
+    int c = 0;
+    for (int d = 1; d <= kDist - 1; ++d) c += (((j - d) % SPP + SPP) % SPP == SPP - 1) ? 1 : 0;
+    return c;
+}
 
 struct F16sArgs {
     const char* in;       // S32, NSM slabs per position
@@ -115,6 +169,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     static_assert(CT * KS * PS == 4 && NT >= KS, "4 waves");
     static_assert(PJ == 0 || NSP == 0, "a producer / consumer of the separate projection has no projection slabs");
     constexpr int NPW = PJ == 1 ? NSM * C16 : 0;  // projection items (centre tap of every k-step)
+    // hand-issued stores per wave and epilogue (the S32 output path: 4 per finished tile; the head / fp32 paths are left to the
+    // compiler and not counted, which only makes the waits stricter)
+    constexpr int NSTW = (AF_F16S_STW && !OUT32 && HD == 0) ? 4 * (KS == 2 ? NFIN : NT) : 0;
+    static_assert(4 * (kDist - 2) + 4 + 2 * NSTW < 64, "vmcnt is a 6-bit field");
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ct = wv % CT, ks = (wv / CT) % KS, ps = wv / (CT * KS);
@@ -256,6 +314,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #ifdef AF_F16S_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    int done = 0;                                                            // positions finished by this wave
     for (; pos < A.batch; pos += gridDim.x) {
         AF_T(tp0);
         if (!XPOS) { AF_FIRST_ITEM(cur) }
@@ -313,9 +372,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     const int issued = NI - 1 < 4 ? NI - 1 : 4;
                     AF_T(tw0);
                     if (more) {
-                        if (issued == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 2) + 4) : "memory");
-                        else if (issued == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 2) + 1) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kDist - 2)) : "memory");
+                        // Stores in flight: vmcnt also counts stores and a wave's operations retire in issue order (probed:
+                        // tools/probes/vmcnt_order.hip), so a plain count would make this wait sit out the HBM write
+                        // acknowledgements of the previous position's epilogue — those stores are YOUNGER than the pieces
+                        // awaited here whenever the pieces of slab t+1 were requested before that epilogue, i.e. for the
+                        // first kDist - 1 slabs after it.  EPW = the epilogues inside that window (static in j), capped by the
+                        // positions this wave has finished; each left NSTW hand-issued stores behind.
+                        const int EPW = epilogues_in_window(j, SPP);                       // (j is static: the loop is unrolled)
+                        const int BASE = 4 * (kDist - 2) + (issued == 4 ? 4 : (issued == 1 ? 1 : 0));
+                        const int live = (EPW == 0 || NSTW == 0 || (A.abl & 2)) ? 0 : (done < EPW ? done : EPW);
+                        if (live == 0) wait_vmcnt(BASE);
+                        else if (live == 1) wait_vmcnt(BASE + NSTW);
+                        else wait_vmcnt(BASE + 2 * NSTW);
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
@@ -527,13 +595,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         hi[e] = h;
                         lo[e] = (_Float16)(f - (float)h);
                     }
-                    if (ok[jj] && !(A.abl & 2)) {
-                        *reinterpret_cast<h8*>(o + hf * kRowB) = hi;
-                        *reinterpret_cast<h8*>(o + hf * kRowB + kHalfB) = lo;
+                    if (ok[jj] && !(A.abl & 2)) {             // (tile 3 always has valid lanes: the two stores are always issued)
+                        st16(o + hf * kRowB, hi);
+                        st16(o + hf * kRowB + kHalfB, lo);
                     }
                 }
             }
         }
+        ++done;
 #ifdef AF_F16S_TIMING
         {
             AF_T(tp3);
