@@ -1,5 +1,5 @@
 // af_conv_f16s.h — internal interface (inside libaf_net.so) between af_net.hip and af_conv_f16s.hip: the fp16
-// split-operand convolution path of the 11x11 network.  Not part of the C ABI (include/af_net.h is).
+// split-operand convolution path of the network (11x11 and 15x15 boards).  Not part of the C ABI (include/af_net.h is).
 #ifndef AF_CONV_F16S_H
 #define AF_CONV_F16S_H
 
@@ -11,8 +11,10 @@
 
 struct f16s_net;
 
-// variables under their checkpoint names in TF layout (as af_net_set_variable received them); 11x11 boards only
-int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::string, std::vector<float>>& vars);
+// variables under their checkpoint names in TF layout (as af_net_set_variable received them); board sizes 11 (one pseudo-position
+// per board, heads fused) and 15 (two half-board pseudo-positions; the heads run on af_net.hip's kernels from fp32 planes)
+int f16s_supported(int board_size);
+int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const std::map<std::string, std::vector<float>>& vars);
 void f16s_destroy(f16s_net* n);
 // stem + bone/block1 + bone/block2 on stream st
 int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes_dev, int batch);

@@ -43,44 +43,72 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;
-constexpr uint32_t kRowB = kPIX * 16u;          // one unit row: 8 channels x 144 units
-constexpr uint32_t kHalfB = 4u * kRowB;         // the hi (or lo) halves of a 32-channel slab
-constexpr uint32_t kSlabB = 2u * kHalfB;        // 18,432 bytes
+// Board geometry.  A kernel instance works on "pseudo-positions" of at most 128 pixels (4 MFMA pixel tiles): an 11x11 board is
+// one of them; a 15x15 board is two HALVES (pixels 0..127 and 128..224), each with its own LDS window of the unit rows — that
+// is what keeps a 32-channel slab of the ring at ~20 KB on the larger board (a whole 15x15 slab is 32 KB: ring + zero region +
+// exchange would not fit 160 KB).  A workgroup only ever sees one half (the grid is even), so the geometry is static per lane.
+//   HBM ("S32"): [position][C/32 slabs][hi|lo][4 unit rows][ROWU units][8 ch] fp16; pixel n sits at unit n + POFF, the other units
+//   are zero and never written.  LDS slot: the same rows, units [WBASE(h), WBASE(h) + WINU) of each.
+template <int S_> struct Geo;
+template <> struct Geo<11> {
+    static constexpr int S = 11, NPIX = 121, HALVES = 1, POFF = 11;
+    static constexpr uint32_t ROWU = 144, WINU = 144;
+    static constexpr int PR = 2, NPC = 4;                       // LDS-DMA pieces (64 units) per unit row; pieces per wave and slab
+    static constexpr uint32_t PADL = 8, PADR = 8;               // window units LDS-DMA never writes (zeroed once)
+    __host__ __device__ static constexpr uint32_t seg_unit(int seg) { return 8u + 64u * (uint32_t)seg; }    // units 8..71, 72..135
+    __host__ __device__ static constexpr uint32_t wbase(int) { return 0u; }
+};
+template <> struct Geo<15> {
+    static constexpr int S = 15, NPIX = 225, HALVES = 2, POFF = 16;
+    static constexpr uint32_t ROWU = 256, WINU = 160;
+    static constexpr int PR = 3, NPC = 6;                       // units 0..63, 64..127, 96..159 of the window (the third piece overlaps)
+    static constexpr uint32_t PADL = 0, PADR = 0;
+    __host__ __device__ static constexpr uint32_t seg_unit(int seg) { return seg == 0 ? 0u : (seg == 1 ? 64u : 96u); }
+    __host__ __device__ static constexpr uint32_t wbase(int h) { return h ? 96u : 0u; }      // half 1 needs units 128..255
+};
+template <class G> struct Lay {
+    static constexpr uint32_t kRowH = G::ROWU * 16u, kHalfH = 4u * kRowH, kSlabH = 2u * kHalfH;     // HBM: unit row / hi (lo) half / slab
+    static constexpr uint32_t kRowL = G::WINU * 16u, kHalfL = 4u * kRowL, kSlotL = 2u * kHalfL;     // LDS slot
+};
 constexpr uint32_t kLds0 = 256u;                // slack so that unit -1 of a slot stays inside LDS
 #ifndef AF_F16S_DIST
 #define AF_F16S_DIST 3
 #endif
 constexpr int kDist = AF_F16S_DIST;             // prefetch distance in slabs: slab t multiplies while t+1 .. t+kDist land
 constexpr int kRing = kDist + 2;                // LDS slots (see the fragment prefetch in the kernel)
-constexpr uint32_t kZoff = kLds0 + kRing * kSlabB; // all-zero region (edge lanes)
-constexpr uint32_t kBiasOff = kZoff + kSlabB;   // 128 floats
-constexpr uint32_t kScrOff = kBiasOff + 512u;   // k-split exchange
+template <class G> struct Lds {
+    static constexpr uint32_t kZoff = kLds0 + kRing * Lay<G>::kSlotL;    // all-zero region (edge lanes)
+    static constexpr uint32_t kBiasOff = kZoff + Lay<G>::kSlotL;         // 128 floats
+    static constexpr uint32_t kScrOff = kBiasOff + 512u;                 // k-split exchange
+};
+// (11x11 only: the stem, the fused heads and the dense kernels below)
+constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;
+constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB;
 
-// Build-time variants (A/B'ed by tools/probe_f16s_ab.py; the defaults are what measured best):
-//   AF_F16S_STW       1: the epilogue's stores stay in flight across the next position's first LDS-DMA waits (see "stores in flight")
-//   AF_F16S_NT_STORE  1: the activation stores carry the nt (streaming) hint
-//   AF_F16S_NT_LOAD   1: the LDS-DMA slab loads carry the nt hint
-#ifndef AF_F16S_STW
-#define AF_F16S_STW 1
-#endif
+// Build-time variants (A/B'ed by tools/probe_f16s_ab.py on 4096 positions, r3_06 / r3_08; the defaults are what measured best):
+//   AF_F16S_NT_LOAD    1: the LDS-DMA slab loads carry the nt (streaming) hint: 1.385 -> 1.357 ms per forward
+//   AF_F16S_MAIN_FIRST 1: a position's 3x3 slabs stream before the slabs of the folded 1x1 projection: 1.357 -> 1.352 ms, and
+//                         |dv| 1.5e-6 -> 8.7e-7 (the small projection terms are added last)
+//   AF_F16S_NT_STORE   1: nt hint on the activation stores: no gain (1.421 vs 1.421)
+// Tried and removed (r3): leaving the epilogue's stores in flight across the next position's first LDS-DMA waits (vmcnt counts
+// stores too and a wave's operations retire in issue order — tools/probes/vmcnt_order.hip — so the counts can be relaxed by the
+// number of younger stores): correct, 1.421 vs 1.421 ms — the waits do not sit on store acknowledgements; the epilogue is
+// VALU-bound (profiles/r3_07).  Stores issued by hand in an asm block: corrupt activations (a hazard the compiler cannot see).
 #ifndef AF_F16S_NT_STORE
 #define AF_F16S_NT_STORE 0
 #endif
 #ifndef AF_F16S_NT_LOAD
-#define AF_F16S_NT_LOAD 0
+#define AF_F16S_NT_LOAD 1
+#endif
+#ifndef AF_F16S_MAIN_FIRST
+#define AF_F16S_MAIN_FIRST 1
 #endif
 
-// 16-byte store issued by hand: exactly one vmcnt-counted instruction, invisible to the compiler's own wait-count bookkeeping
-// (which is what lets the kernel count it in its s_waitcnt immediates)
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st16(void* gdst, const h8& v) {
-    u32x4 r;
-    __builtin_memcpy(&r, &v, 16);
 #if AF_F16S_NT_STORE
-    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(gdst), "v"(r) : "memory");
+    __builtin_nontemporal_store(v, reinterpret_cast<h8*>(gdst));
 #else
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(gdst), "v"(r) : "memory");
+    *reinterpret_cast<h8*>(gdst) = v;
 #endif
 }
 
@@ -124,14 +152,6 @@ __device__ unsigned long long g_f16s_cycles[10][512][4][9];
 #define AF_TACC(slot, a, b)
 #endif
 
-// epilogues (one after the last slab of every position) that lie between the request of slab t+1 — made during slab
-// t+1-kDist — and the barrier inside slab t, for slab j = t mod SPP of a position
-constexpr int epilogues_in_window(int j, int SPP) {
-    int c = 0;
-    for (int d = 1; d <= kDist - 1; ++d) c += (((j - d) % SPP + SPP) % SPP == SPP - 1) ? 1 : 0;
-    return c;
-}
-
 struct F16sArgs {
     const char* in;       // S32, NSM slabs per position
     const char* in2;      // S32, NSP slabs per position (block input for the folded 1x1 projection)
@@ -157,9 +177,14 @@ struct F16sArgs {
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
 };
 
-template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD>
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_conv_f16s(F16sArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using L = Lay<G>;
+    constexpr uint32_t kRowH = L::kRowH, kHalfH = L::kHalfH, kSlabH = L::kSlabH, kRowL = L::kRowL, kHalfL = L::kHalfL, kSlotL = L::kSlotL;
+    constexpr uint32_t kZoff = Lds<G>::kZoff, kBiasOff = Lds<G>::kBiasOff, kScrOff = Lds<G>::kScrOff;
+    constexpr int NPC = G::NPC, HV = G::HALVES;
+    static_assert(HD == 0 || G::S == 11, "the fused head inputs are laid out for 11x11");
     constexpr int NT = 4 / PS;                    // pixel tiles per wave
     constexpr int C16 = 2 / KS;                   // 16-channel k-steps per slab and wave
     constexpr int ITP = C16, ITM = 9 * C16;       // items (k-step x tap) per projection / main slab
@@ -169,43 +194,49 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     static_assert(CT * KS * PS == 4 && NT >= KS, "4 waves");
     static_assert(PJ == 0 || NSP == 0, "a producer / consumer of the separate projection has no projection slabs");
     constexpr int NPW = PJ == 1 ? NSM * C16 : 0;  // projection items (centre tap of every k-step)
-    // hand-issued stores per wave and epilogue (the S32 output path: 4 per finished tile; the head / fp32 paths are left to the
-    // compiler and not counted, which only makes the waits stricter)
-    constexpr int NSTW = (AF_F16S_STW && !OUT32 && HD == 0) ? 4 * (KS == 2 ? NFIN : NT) : 0;
-    static_assert(4 * (kDist - 2) + 4 + 2 * NSTW < 64, "vmcnt is a 6-bit field");
+    static_assert(NPC * (kDist - 1) < 64, "vmcnt is a 6-bit field");
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ct = wv % CT, ks = (wv / CT) % KS, ps = wv / (CT * KS);
     const int ctg = (int)blockIdx.y * CT + ct, nso = (int)gridDim.y * CT;
     const uint32_t lds = (uint32_t)(uintptr_t)smem;
 
-    int pos = blockIdx.x;
-    if (pos >= A.batch) return;
+    // pseudo-position q = HALVES * position + half; this workgroup takes q0, q0 + gridDim.x, ... (gridDim.x is a multiple of
+    // HALVES, so the half — and with it every lane's pixel, window and edge flags — is fixed for the whole launch)
+    const int nq = A.batch * HV;
+    int qpos = blockIdx.x;
+    if (qpos >= nq) return;
+    const int hv = HV == 1 ? 0 : qpos % HV;
+    const uint32_t wsrc = G::wbase(hv) * 16u;          // byte offset of the half's window inside a unit row (HBM)
     AF_T(t_entry);
 
     // slab j of a position: the NSP slabs of the projection input first, then the NSM slabs of the 3x3 input (the other
     // order — long slabs first, so that the epilogue's stores have more time before the next wait on vmcnt — measured
     // 1.58 vs 1.55 ms per forward and moved |dp| from 6.0e-6 to 8.1e-6)
-    auto slab_src = [&](int p, int j) -> const char* {
-        return j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabB : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabB;
+    auto slab_src = [&](int qq, int j) -> const char* {             // (qq: pseudo-position)
+        const int p = HV == 1 ? qq : qq / HV;
+        if (AF_F16S_MAIN_FIRST) return (j < NSM ? A.in + ((size_t)p * NSM + j) * kSlabH : A.in2 + ((size_t)p * NSP + (j - NSM)) * kSlabH) + wsrc;
+        return (j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabH : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabH) + wsrc;
     };
-    // piece wv + 4q of a slab, q = 0..3: every wave issues exactly 4 LDS-DMA instructions (1 KB each) per slab — one per item,
-    // the rest behind the slab's last item — which is what lets the counted "s_waitcnt vmcnt" in front of each barrier say
-    // "everything but what was requested after slab t+1 has landed" (see the last-item branch below).  A piece is 64 units
-    // of one unit row: units 8..71 or 72..135 (pixels sit at units 11..131; the other units of a slot are zeroed once
-    // and never written).
-    auto dma_piece = [&](const char* src, uint32_t slot_off, int q) {
-        const int piece = wv + 4 * q;
-        const uint32_t off = (uint32_t)(piece >> 3) * kHalfB + (uint32_t)((piece >> 1) & 3) * kRowB + (8u + 64u * (piece & 1)) * 16u;
-        glds16(src + off + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + off)));
+    // piece wv + 4k of a slab, k = 0..NPC-1: every wave issues exactly NPC LDS-DMA instructions (1 KB each) per slab — one per
+    // item, the rest behind the slab's last item — which is what lets the counted "s_waitcnt vmcnt" in front of each barrier
+    // say "everything but what was requested after slab t+1 has landed" (see the last-item branch below).  A piece is 64
+    // units of one unit row of the window (11x11: units 8..71 / 72..135, pixels sit at units 11..131 and the other units of a
+    // slot are zeroed once and never written; 15x15: units 0..63 / 64..127 / 96..159 of the half's 160-unit window).
+    auto dma_piece = [&](const char* src, uint32_t slot_off, int k) {
+        const int piece = wv + 4 * k, row = piece / G::PR;                    // row: 0..7 = (hi|lo, unit row)
+        const uint32_t su = G::seg_unit(piece % G::PR) * 16u;
+        const uint32_t offh = (uint32_t)(row >> 2) * kHalfH + (uint32_t)(row & 3) * kRowH + su;
+        const uint32_t offl = (uint32_t)(row >> 2) * kHalfL + (uint32_t)(row & 3) * kRowL + su;
+        glds16(src + offh + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + offl)));
     };
-    // slab number `idx` of the stream this workgroup consumes (positions pos0, pos0 + gridDim.x, ...; SPP slabs each)
-    const int pos0 = pos;
+    // slab number `idx` of the stream this workgroup consumes (pseudo-positions q0, q0 + gridDim.x, ...; SPP slabs each)
+    const int q0 = qpos;
     auto stream_src = [&](uint32_t idx) -> const char* {
-        const int p = pos0 + (int)(idx / SPP) * (int)gridDim.x, j = (int)(idx % SPP);
+        const int p = q0 + (int)(idx / SPP) * (int)gridDim.x, j = (int)(idx % SPP);
         return slab_src(p, j);
     };
-    const uint32_t nslabs = (uint32_t)((A.batch - pos0 + (int)gridDim.x - 1) / (int)gridDim.x) * SPP;
+    const uint32_t nslabs = (uint32_t)((nq - q0 + (int)gridDim.x - 1) / (int)gridDim.x) * SPP;
 
     // Start-up (5-8 us of every launch, r2_39): the longest latencies first — the first kDist slabs (HBM -> LDS-DMA), then the
     // weights (L2) — and under them the LDS zeroing: only what LDS-DMA never writes (slack, the pad units 0..7 and 136..143 of
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int d = 0; d < kDist; ++d) {
         if ((uint32_t)d < nslabs) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dma_piece(stream_src(d), (uint32_t)d * kSlabB, q);
+            for (int k = 0; k < NPC; ++k) dma_piece(stream_src(d), (uint32_t)d * kSlotL, k);
         }
     }
 
@@ -249,11 +280,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         for (int r = 0; r < 8; ++r) hb[r] = A.hbias[8 * kg + r];
     }
     if (threadIdx.x < kLds0 / 16) *reinterpret_cast<uint4*>(smem + threadIdx.x * 16) = uint4{0, 0, 0, 0};
-    for (uint32_t u = threadIdx.x; u < (uint32_t)kRing * 128u; u += 256) {      // (slot, unit row 0..7, side, unit 0..7)
-        const uint32_t off = kLds0 + (u >> 7) * kSlabB + ((u >> 4) & 7u) * kRowB + (((u >> 3) & 1u) ? 136u * 16u : 0u) + (u & 7u) * 16u;
-        *reinterpret_cast<uint4*>(smem + off) = uint4{0, 0, 0, 0};
+    if (G::PADL + G::PADR > 0) {
+        static_assert(G::PADL + G::PADR == 0 || (G::PADL == 8 && G::PADR == 8), "pad zeroing is written for 8 + 8 units");
+        for (uint32_t u = threadIdx.x; u < (uint32_t)kRing * 128u; u += 256) {      // (slot, unit row 0..7, side, unit 0..7)
+            const uint32_t off = kLds0 + (u >> 7) * kSlotL + ((u >> 4) & 7u) * kRowL + (((u >> 3) & 1u) ? (G::WINU - 8u) * 16u : 0u) + (u & 7u) * 16u;
+            *reinterpret_cast<uint4*>(smem + off) = uint4{0, 0, 0, 0};
+        }
     }
-    for (uint32_t u = threadIdx.x; u < kSlabB / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
+    for (uint32_t u = threadIdx.x; u < kSlotL / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
     if (threadIdx.x < CT * 32) reinterpret_cast<float*>(smem + kBiasOff)[threadIdx.x] = A.bias[(int)blockIdx.y * CT * 32 + threadIdx.x];
     // lane geometry per pixel tile: LDS byte base of tap (0,0) in slot 0, zero-region twin, output unit
     uint32_t lb[NT], zb[NT];
@@ -261,14 +295,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     bool ok[NT], edgeL[NT], edgeR[NT];
 #pragma unroll
     for (int jj = 0; jj < NT; ++jj) {
-        const int n = 32 * (ps * NT + jj) + nn;
-        ok[jj] = n < kNPIX;
-        const int nc = ok[jj] ? n : 0;
+        const int n = 128 * hv + 32 * (ps * NT + jj) + nn;
+        ok[jj] = n < G::NPIX;
+        const int nc = ok[jj] ? n : 128 * hv;                                // (an invalid lane works on the half's first pixel)
         pix[jj] = nc;
-        const int x = nc % kS;
-        edgeL[jj] = x == 0; edgeR[jj] = x == kS - 1;
-        // pixel nc sits at unit nc + 11; tap (ky,kx) reads unit nc + 11 + (ky-1)*11 + (kx-1) = (nc - 1) + ky*11 + kx
-        lb[jj] = kLds0 + (uint32_t)((KS == 2 ? 2 * ks : 0) + kg) * kRowB + (uint32_t)(nc * 16) - 16u;
+        const int x = nc % G::S;
+        edgeL[jj] = x == 0; edgeR[jj] = x == G::S - 1;
+        // pixel nc sits at unit nc + POFF of a row; tap (ky,kx) reads unit nc + POFF + (ky-1)*S + (kx-1) = u0 + ky*S + kx with
+        // u0 = nc + POFF - S - 1, i.e. window unit u0 - WBASE (11x11: nc - 1; 15x15: nc - 0 / nc - 96)
+        lb[jj] = kLds0 + (uint32_t)((KS == 2 ? 2 * ks : 0) + kg) * kRowL + (uint32_t)((nc + G::POFF - G::S - 1 - (int)G::wbase(hv)) * 16);
         zb[jj] = kZoff + (lb[jj] & 255u);
     }
 #pragma unroll
@@ -290,12 +325,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     auto rd = [](const char* sm, bool proj, int it, int p, uint32_t c_, uint32_t l_, uint32_t r_) -> h8 {
         const int c = proj ? it : it / 9, tap = proj ? 4 : it % 9, ky = tap / 3, kx = tap % 3;
         const uint32_t base = kx == 0 ? l_ : (kx == 2 ? r_ : c_);
-        const uint32_t imm = (uint32_t)p * kHalfB + (KS == 1 ? 2u * c * kRowB : 0u) + (uint32_t)(ky * kS + kx) * 16u;
+        const uint32_t imm = (uint32_t)p * kHalfL + (KS == 1 ? 2u * c * kRowL : 0u) + (uint32_t)(ky * G::S + kx) * 16u;
         return *reinterpret_cast<const h8*>(sm + base + imm);
     };
 
     uint32_t t = 0;
-    uint32_t cur = 0u, nxd = (uint32_t)kDist * kSlabB;        // ring slots of slab t and of slab t + kDist
+    uint32_t cur = 0u, nxd = (uint32_t)kDist * kSlotL;        // ring slots of slab t and of slab t + kDist
     // Fragments are double buffered per item and prefetched one item ahead ACROSS slab (and position) boundaries: the
     // wait + barrier that publishes slab t+1 sits in front of the LAST item of slab t, whose MFMAs then cover the LDS
     // latency of slab t+1's first fragments.  (Hence kRing = kDist + 2: the slot that LDS-DMA refills during slab t is
@@ -307,15 +342,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #define AF_FIRST_ITEM(slot)                                                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                          \
         const uint32_t c_ = lb[jj] + (slot), l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_;         \
-        fr[0][jj][0] = rd(smem, NSP > 0, 0, 0, c_, l_, r_);                                                      \
-        fr[0][jj][1] = rd(smem, NSP > 0, 0, 1, c_, l_, r_);                                                      \
+        fr[0][jj][0] = rd(smem, NSP > 0 && !AF_F16S_MAIN_FIRST, 0, 0, c_, l_, r_);                               \
+        fr[0][jj][1] = rd(smem, NSP > 0 && !AF_F16S_MAIN_FIRST, 0, 1, c_, l_, r_);                               \
     }
     if (XPOS) { AF_FIRST_ITEM(0u) }
 #ifdef AF_F16S_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    int done = 0;                                                            // positions finished by this wave
-    for (; pos < A.batch; pos += gridDim.x) {
+    for (; qpos < nq; qpos += gridDim.x) {
+        const int pos = HV == 1 ? qpos : qpos / HV;
         AF_T(tp0);
         if (!XPOS) { AF_FIRST_ITEM(cur) }
 #undef AF_FIRST_ITEM
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
             for (int jf = 0; jf < NFIN; ++jf) {
                 const int tile = ps * NT + (KS == 2 ? ks * NFIN : 0) + jf;
-                const f32x4* src = reinterpret_cast<const f32x4*>(A.pbuf) + ((((size_t)pos * nso + ctg) * 4 + tile) * 4) * 64 + lane;
+                const f32x4* src = reinterpret_cast<const f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + tile) * 4) * 64 + lane;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) padd[jf][q] = src[q * 64];
             }
@@ -341,14 +376,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
 #pragma clang loop unroll(full)
         for (int j = 0; j < SPP; ++j) {
-            const bool proj = j < NSP, nproj = (j + 1) % SPP < NSP;        // this slab / the next slab of the stream
+            // this slab / the next slab of the stream: a projection slab?  (ms = index among the position's 3x3 slabs)
+            const bool proj = AF_F16S_MAIN_FIRST ? j >= NSM : j < NSP;
+            const bool nproj = AF_F16S_MAIN_FIRST ? (j + 1) % SPP >= NSM : (j + 1) % SPP < NSP;
+            const int ms = AF_F16S_MAIN_FIRST ? j : j - NSP, pslab = AF_F16S_MAIN_FIRST ? j - NSM : j;
             const int NI = proj ? ITP : ITM;
-            const int ibase = proj ? j * ITP : NSP * ITP + (j - NSP) * ITM;
+            // ibase: the slab's first item in the weight array (packed projection items first); seq: its running number within the
+            // position (fragment double-buffer parity)
+            const int ibase = proj ? pslab * ITP : NSP * ITP + ms * ITM;
+            const int seq = AF_F16S_MAIN_FIRST ? (proj ? NSM * ITM + pslab * ITP : ms * ITM) : ibase;
             // slab t + kDist of the stream: j is static (the loop is unrolled), so which position / slab that is costs no division
-            const int npos = pos + ((j + kDist) / SPP) * (int)gridDim.x;
-            const bool more = npos < A.batch && !(A.abl & 1);
-            const char* nsrc = slab_src((A.abl & 4) ? pos0 : (more ? npos : pos), (j + kDist) % SPP);   // abl bit 2: the first position's slabs again (L2-hot)
-            const uint32_t nx1 = cur + kSlabB == kRing * kSlabB ? 0u : cur + kSlabB;     // slot of slab t+1
+            const int npos = qpos + ((j + kDist) / SPP) * (int)gridDim.x;
+            const bool more = npos < nq && !(A.abl & 1);
+            const char* nsrc = slab_src((A.abl & 4) ? q0 : (more ? npos : qpos), (j + kDist) % SPP);   // abl bit 2: the first position's slabs again (L2-hot)
+            const uint32_t nx1 = cur + kSlotL == kRing * kSlotL ? 0u : cur + kSlotL;     // slot of slab t+1
             uint32_t bC[NT], bL[NT], bR[NT];
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
@@ -358,7 +399,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
 #pragma clang loop unroll(full)
             for (int it = 0; it < NI; ++it) {
-                const int b = (ibase + it) & 1;
+                const int b = (seq + it) & 1;
                 if (it + 1 < NI) {
 #pragma unroll
                     for (int jj = 0; jj < NT; ++jj) {
@@ -368,22 +409,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 } else {
                     // last item of slab t: slab t+1 must have landed for every wave — only what was requested AFTER its pieces
                     // may still be in flight: kDist - 2 whole slabs and the pieces of slab t + kDist this slab has issued
-                    // so far (one per earlier item, at most 4) — then fetch slab t+1's first fragments
-                    const int issued = NI - 1 < 4 ? NI - 1 : 4;
+                    // so far (one per earlier item, at most NPC) — then fetch slab t+1's first fragments
+                    const int issued = NI - 1 < NPC ? NI - 1 : NPC;
                     AF_T(tw0);
                     if (more) {
-                        // Stores in flight: vmcnt also counts stores and a wave's operations retire in issue order (probed:
-                        // tools/probes/vmcnt_order.hip), so a plain count would make this wait sit out the HBM write
-                        // acknowledgements of the previous position's epilogue — those stores are YOUNGER than the pieces
-                        // awaited here whenever the pieces of slab t+1 were requested before that epilogue, i.e. for the
-                        // first kDist - 1 slabs after it.  EPW = the epilogues inside that window (static in j), capped by the
-                        // positions this wave has finished; each left NSTW hand-issued stores behind.
-                        const int EPW = epilogues_in_window(j, SPP);                       // (j is static: the loop is unrolled)
-                        const int BASE = 4 * (kDist - 2) + (issued == 4 ? 4 : (issued == 1 ? 1 : 0));
-                        const int live = (EPW == 0 || NSTW == 0 || (A.abl & 2)) ? 0 : (done < EPW ? done : EPW);
-                        if (live == 0) wait_vmcnt(BASE);
-                        else if (live == 1) wait_vmcnt(BASE + NSTW);
-                        else wait_vmcnt(BASE + 2 * NSTW);
+                        wait_vmcnt(NPC * (kDist - 2) + issued);
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
@@ -416,7 +446,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     for (int jj = 0; jj < NT; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fr[b][jj][0], acc[jj], 0, 0, 0);
                 }
                 if (PJ == 1 && !proj && it % 9 == 4) {                     // centre tap: the 1x1 projection reads the very same fragments
-                    const int pi = (j - NSP) * C16 + it / 9;
+                    const int pi = ms * C16 + it / 9;
                     const h8 ph = PW[2 * pi], pl = PW[2 * pi + 1];
 #pragma unroll
                     for (int jj = 0; jj < NT; ++jj) pac[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, fr[b][jj][0], pac[jj], 0, 0, 0);
@@ -431,19 +461,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-                // slab t + kDist (its slot was slab t-2's: free since the barrier inside slab t-1): this wave's 4 pieces of 1 KB,
+                // slab t + kDist (its slot was slab t-2's: free since the barrier inside slab t-1): this wave's NPC pieces of 1 KB,
                 // one per item, the rest behind the last item
                 if (more) {
-                    if (it < NI - 1 && it < 4) dma_piece(nsrc, nxd, it);
+                    if (it < NI - 1 && it < NPC) dma_piece(nsrc, nxd, it);
                     if (it == NI - 1) {
 #pragma unroll
-                        for (int q = (NI - 1 < 4 ? NI - 1 : 4); q < 4; ++q) dma_piece(nsrc, nxd, q);
+                        for (int k = (NI - 1 < NPC ? NI - 1 : NPC); k < NPC; ++k) dma_piece(nsrc, nxd, k);
                     }
                 }
             }
             ++t;
             cur = nx1;
-            nxd = nxd + kSlabB == kRing * kSlabB ? 0u : nxd + kSlabB;
+            nxd = nxd + kSlotL == kRing * kSlotL ? 0u : nxd + kSlotL;
         }
         if (XPOS && (NIT & 1)) {                                             // keep the fragment parity static per position
 #pragma unroll
@@ -499,7 +529,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
                 if (KS == 2 && (jj / NFIN) != ks) continue;
-                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)pos * nso + ctg) * 4 + ps * NT + jj) * 4) * 64 + lane;
+                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + ps * NT + jj) * 4) * 64 + lane;
                 if (!(A.abl & 2)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -577,14 +607,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     }
                 }
             } else if (OUT32) {
-                const int y = pix[jj] / kS, x = pix[jj] - y * kS;
+                const int y = pix[jj] / G::S, x = pix[jj] - y * G::S;
                 float* o = A.out32 + ((size_t)pos * (nso * 32) + 32 * ctg + 16 * kg) * A.PP + (y + 1) * A.WP + x + 1;
                 if (ok[jj] && !(A.abl & 2)) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[(size_t)r * A.PP] = v[r];
                 }
             } else {
-                char* o = A.out + ((size_t)pos * nso + ctg) * kSlabB + (uint32_t)(2 * kg) * kRowB + (uint32_t)(pix[jj] + kS) * 16u;
+                char* o = A.out + ((size_t)pos * nso + ctg) * kSlabH + (uint32_t)(2 * kg) * kRowH + (uint32_t)(pix[jj] + G::POFF) * 16u;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     h8 hi, lo;
@@ -596,13 +626,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         lo[e] = (_Float16)(f - (float)h);
                     }
                     if (ok[jj] && !(A.abl & 2)) {             // (tile 3 always has valid lanes: the two stores are always issued)
-                        st16(o + hf * kRowB, hi);
-                        st16(o + hf * kRowB + kHalfB, lo);
+                        st16(o + hf * kRowH, hi);
+                        st16(o + hf * kRowH + kHalfH, lo);
                     }
                 }
             }
         }
-        ++done;
 #ifdef AF_F16S_TIMING
         {
             AF_T(tp3);
@@ -620,26 +649,30 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #endif
 }
 
-// 5x5 stem (3 -> 32, SAME) + bias + ELU (network.py:63) on the VALU (2,400 MAC per pixel), output split into S32.
-// planes fp32 [B][3][11][11] (utils.py:256 board_to_inputs); w [75][32] HWIO.
+// 5x5 stem (3 -> 32, SAME) + bias + ELU (network.py:63) on the VALU (2,400 MAC per pixel), output split into S32 — any board
+// geometry (the path of the 15x15 boards; 11x11 runs af_stem_mfma_f16s below).  planes fp32 [B][3][S][S] (utils.py:256
+// board_to_inputs); w [75][32] HWIO.
+template <class G>
 __global__ __launch_bounds__(256) void af_stem_f16s(const float* __restrict__ planes, const float* __restrict__ w,
                                                     const float* __restrict__ bias, char* __restrict__ out, int batch) {
-    __shared__ float sx[3 * 15 * 15];
+    constexpr int S = G::S, NPIX = G::NPIX, SP = S + 4;
+    constexpr uint32_t kRowH = Lay<G>::kRowH, kHalfH = Lay<G>::kHalfH, kSlabH = Lay<G>::kSlabH;
+    __shared__ float sx[3 * SP * SP];
     __shared__ float sw[75 * 32];
     __shared__ float sb[32];
     const int t = threadIdx.x;
     for (int i = t; i < 75 * 32; i += 256) sw[i] = w[i];
     if (t < 32) sb[t] = bias[t];
-    for (int i = t; i < 3 * 225; i += 256) sx[i] = 0.0f;
+    for (int i = t; i < 3 * SP * SP; i += 256) sx[i] = 0.0f;
     for (int b = blockIdx.x; b < batch; b += gridDim.x) {
         __syncthreads();
-        for (int i = t; i < 3 * kNPIX; i += 256) {
-            const int c = i / kNPIX, p = i - c * kNPIX, y = p / kS, x = p - y * kS;
-            sx[c * 225 + (y + 2) * 15 + x + 2] = planes[(size_t)b * 3 * kNPIX + i];
+        for (int i = t; i < 3 * NPIX; i += 256) {
+            const int c = i / NPIX, p = i - c * NPIX, y = p / S, x = p - y * S;
+            sx[c * SP * SP + (y + 2) * SP + x + 2] = planes[(size_t)b * 3 * NPIX + i];
         }
         __syncthreads();
-        if (t < kNPIX) {
-            const int y = t / kS, x = t - y * kS;
+        if (t < NPIX) {
+            const int y = t / S, x = t - y * S;
             float acc[32];
 #pragma unroll
             for (int co = 0; co < 32; ++co) acc[co] = sb[co];
@@ -647,12 +680,12 @@ __global__ __launch_bounds__(256) void af_stem_f16s(const float* __restrict__ pl
                 for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const float xv = sx[c * 225 + (y + ky) * 15 + x + kx];
+                        const float xv = sx[c * SP * SP + (y + ky) * SP + x + kx];
                         const float* wr = sw + ((ky * 5 + kx) * 3 + c) * 32;
 #pragma unroll
                         for (int co = 0; co < 32; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
                     }
-            char* o = out + (size_t)b * kSlabB + (uint32_t)(t + kS) * 16u;
+            char* o = out + (size_t)b * kSlabH + (uint32_t)(t + G::POFF) * 16u;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 h8 hi, lo;
@@ -663,8 +696,8 @@ __global__ __launch_bounds__(256) void af_stem_f16s(const float* __restrict__ pl
                     hi[e] = h;
                     lo[e] = (_Float16)(f - (float)h);
                 }
-                *reinterpret_cast<h8*>(o + u * kRowB) = hi;
-                *reinterpret_cast<h8*>(o + u * kRowB + kHalfB) = lo;
+                *reinterpret_cast<h8*>(o + u * kRowH) = hi;
+                *reinterpret_cast<h8*>(o + u * kRowH + kHalfH) = lo;
             }
         }
     }
@@ -1021,24 +1054,28 @@ std::vector<_Float16> pack_frags(int nfrag, F&& val) {          // [fragment][hi
     return out;
 }
 
-template <int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ = 0, int HD = 0>
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ = 0, int HD = 0>
 int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     constexpr int NT = 4 / PS;
-    const size_t lds = kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 * (PJ == 1 ? 2 : 1) : 0);
+    constexpr size_t lds = Lds<G>::kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 * (PJ == 1 ? 2 : 1) : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>),
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    const int gx = std::max(1, std::min(a.batch, ncu / gy));
-    hipLaunchKernelGGL((af_conv_f16s<NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>), dim3(gx, gy), dim3(256), lds, st, a);
+    // one workgroup per CU, a multiple of HALVES of them (a workgroup keeps one half of the board for the whole launch)
+    int gx = std::max(1, std::min(a.batch * G::HALVES, ncu / gy));
+    gx = std::max(G::HALVES, gx / G::HALVES * G::HALVES);
+    hipLaunchKernelGGL((af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>), dim3(gx, gy), dim3(256), lds, st, a);
     return 0;
 }
 
 }  // namespace
 
 struct f16s_net {
+    int S = 11;                   // board size: 11 (one pseudo-position per board) or 15 (two halves)
     int max_batch = 0, device = 0, ncu = 256;
     std::vector<void*> allocs;
     float *stem_w = nullptr, *stem_b = nullptr;
@@ -1059,16 +1096,22 @@ struct f16s_net {
     int abl = 0;
 };
 
-int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::string, std::vector<float>>& V) {
+int f16s_supported(int board_size) { return board_size == 11 || board_size == 15; }
+
+int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const std::map<std::string, std::vector<float>>& V) {
+    if (!f16s_supported(board_size)) return -1;
     FS_HIP_OK(hipSetDevice(device));
     f16s_net* n = new f16s_net();
-    n->max_batch = max_batch; n->device = device;
+    n->S = board_size; n->max_batch = max_batch; n->device = device;
+    const bool s11 = board_size == 11;
+    const int halves = s11 ? 1 : 2;
+    const size_t slab_bytes = s11 ? Lay<Geo<11>>::kSlabH : Lay<Geo<15>>::kSlabH;
     FS_HIP_OK(hipDeviceGetAttribute(&n->ncu, hipDeviceAttributeMultiprocessorCount, device));
     int rc = 0;
     auto get = [&](const std::string& k) -> const std::vector<float>& { return V.at(k); };
     rc = dev_upload(n->allocs, &n->stem_w, get("bone/conv1/kernel").data(), 75 * 32 * 4);
     if (!rc) rc = dev_upload(n->allocs, &n->stem_b, get("bone/conv1/bias").data(), 32 * 4);
-    if (!rc) {       // [k-step s][hi|lo][lane][8]: MFMA row m -> cout perm(m); k = 8*(lane>>5) + e of group g = 2s + (lane>>5) = cin*5 + ky, tap kx = e
+    if (!rc && s11) {       // [k-step s][hi|lo][lane][8]: MFMA row m -> cout perm(m); k = 8*(lane>>5) + e of group g = 2s + (lane>>5) = cin*5 + ky, tap kx = e
         const std::vector<float>& ks = get("bone/conv1/kernel");         // HWIO [5][5][3][32]
         const float sc = pick_scale(ks, nullptr);
         std::vector<_Float16> pk((size_t)8 * 2 * 64 * 8, (_Float16)0.0f);
@@ -1100,7 +1143,7 @@ int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::s
             rc = dev_upload(n->allocs, &n->pw[2 * b], pp.data(), pp.size() * 2);
             n->inv_scale_p[2 * b] = 1.0f / sp;
             void* q = nullptr;
-            const size_t bytes = (size_t)max_batch * (L2.cout / 32) * 4 * 4 * 64 * 16;
+            const size_t bytes = (size_t)max_batch * halves * (L2.cout / 32) * 4 * 4 * 64 * 16;      // [pseudo-position][cout tile][4 pixel tiles][4][64] float4
             if (!rc) { FS_HIP_OK(hipMalloc(&q, bytes)); n->allocs.push_back(q); n->pbuf[b] = (float*)q; }
         }
 
@@ -1113,7 +1156,7 @@ int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::s
     }
     auto act = [&](char** p, int ch) -> int {
         void* q = nullptr;
-        const size_t bytes = (size_t)max_batch * (ch / 32) * kSlabB;
+        const size_t bytes = (size_t)max_batch * (ch / 32) * slab_bytes;
         FS_HIP_OK(hipMalloc(&q, bytes));
         FS_HIP_OK(hipMemset(q, 0, bytes));           // the zero units of S32 are never written again
         n->allocs.push_back(q);
@@ -1125,7 +1168,7 @@ int f16s_create(f16s_net** out, int max_batch, int device, const std::map<std::s
         rc = act(&n->g[b], kLayers[2 * b].cout);
         if (!rc && b != 2 && b != 4) rc = act(&n->o[b], kLayers[2 * b + 1].cout);
     }
-    if (!rc) {          // heads: value/conv [32][4], value/fc1 [4*121][64], value/fc2 [64][1]; policy/conv [32][16], policy/fc [16*121][121]
+    if (!rc && s11) {   // heads: value/conv [32][4], value/fc1 [4*121][64], value/fc2 [64][1]; policy/conv [32][16], policy/fc [16*121][121]
         const char* cname[2] = {"value/conv", "policy/conv"};
         const int nco[2] = {4, 16};
         for (int h = 0; h < 2 && !rc; ++h) {
@@ -1186,6 +1229,28 @@ void f16s_destroy(f16s_net* n) {
 
 void f16s_set_ablation(f16s_net* n, int bits) { if (n) n->abl = bits; }
 
+// the ten layers on one board geometry.  <NSM, NSP, CT, KS, PS, OUT32, XACC[, PJ, HD]>: XACC wherever weights + 2 x accumulators +
+// fragments fit 512 registers; the fused head variants (HD) exist for 11x11 only
+template <class G>
+static int launch_layer_g(f16s_net* n, hipStream_t st, int li, const F16sArgs& a, int head) {
+    switch (li) {
+        case 0: return launch_cfg<G, 1, 0, 2, 1, 2, false, true>(st, a, 1, n->ncu);
+        case 1: return launch_cfg<G, 2, 1, 2, 1, 2, false, true>(st, a, 1, n->ncu);
+        case 2: return launch_cfg<G, 2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
+        case 3: return launch_cfg<G, 4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
+        case 4: return launch_cfg<G, 4, 0, 1, 2, 2, false, false, 1>(st, a, 1, n->ncu);   // (no XACC: weights + projection weights + 3 accumulator sets would spill)
+        case 5:
+            if constexpr (G::S == 11) { if (head == 0) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 1>(st, a, 1, n->ncu); }
+            return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);         // (one pixel tile per wave, whole K: no k-split exchange)
+        case 6: return launch_cfg<G, 4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
+        case 7: return launch_cfg<G, 2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
+        case 8: return launch_cfg<G, 2, 0, 1, 1, 4, false, true, 1>(st, a, 1, n->ncu);
+        default:
+            if constexpr (G::S == 11) { if (head == 1) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 2>(st, a, 1, n->ncu); }
+            return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
+    }
+}
+
 static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, const char* in2, char* out, float* out32, int batch,
                         int WP, int PP, int head = -1) {
     F16sArgs a;
@@ -1194,27 +1259,15 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
     a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xff) | (li << 8);
     a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
-    switch (li) {
-        // <NSM, NSP, CT, KS, PS, OUT32, XACC>: XACC wherever weights + 2 x accumulators + fragments fit 512 registers
-        case 0: return launch_cfg<1, 0, 2, 1, 2, false, true>(st, a, 1, n->ncu);
-        case 1: return launch_cfg<2, 1, 2, 1, 2, false, true>(st, a, 1, n->ncu);
-        case 2: return launch_cfg<2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
-        case 3: return launch_cfg<4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
-        case 4: return launch_cfg<4, 0, 1, 2, 2, false, false, 1>(st, a, 1, n->ncu);   // (no XACC: weights + projection weights + 3 accumulator sets would spill)
-        case 5: return head == 0 ? launch_cfg<1, 0, 1, 1, 4, true, true, 2, 1>(st, a, 1, n->ncu)
-                                 : launch_cfg<1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);   // (one pixel tile per wave, whole K: no k-split exchange)
-        case 6: return launch_cfg<4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
-        case 7: return launch_cfg<2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
-        case 8: return launch_cfg<2, 0, 1, 1, 4, false, true, 1>(st, a, 1, n->ncu);
-        default: return head == 1 ? launch_cfg<1, 0, 1, 1, 4, true, true, 2, 2>(st, a, 1, n->ncu)
-                                  : launch_cfg<1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
-    }
+    return n->S == 11 ? launch_layer_g<Geo<11>>(n, st, li, a, head) : launch_layer_g<Geo<15>>(n, st, li, a, -1);
 }
 
 int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes, int batch) {
     if (!n || batch < 1 || batch > n->max_batch) return -1;
-    if (n->abl & 16)    // A/B: the VALU stem
-        hipLaunchKernelGGL(af_stem_f16s, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
+    if (n->S == 15)
+        hipLaunchKernelGGL(af_stem_f16s<Geo<15>>, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
+    else if (n->abl & 16)    // A/B: the VALU stem
+        hipLaunchKernelGGL(af_stem_f16s<Geo<11>>, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
     else
         hipLaunchKernelGGL(af_stem_mfma_f16s, dim3(std::min(batch, 1024)), dim3(256), 0, st, planes, n->stem_wm, n->stem_b, n->stem_inv_scale,
                            n->f0, batch);
@@ -1246,22 +1299,25 @@ int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP
 }
 
 // debug / tests: activation `which` (0 f0, 1 g1, 2 o1, 3 g2, 4 o2, 5 g3, 6 g4, 7 o4, 8 g5) of the first `batch` positions as
-// fp32 [batch][C][121] on the host (hi + lo).  Returns the channel count or < 0.
+// fp32 [batch][C][S*S] on the host (hi + lo).  Returns the channel count or < 0.
 int f16s_read_activation(f16s_net* n, int which, int batch, float* host) {
     if (!n || batch < 1 || batch > n->max_batch) return -1;
     const char* bufs[9] = {n->f0, n->g[0], n->o[0], n->g[1], n->o[1], n->g[2], n->g[3], n->o[3], n->g[4]};
     const int chans[9] = {32, 64, 64, 128, 128, 32, 64, 64, 32};
     if (which < 0 || which > 8) return -1;
     const int C = chans[which];
-    std::vector<_Float16> h((size_t)batch * (C / 32) * kSlabB / 2);
+    const bool s11 = n->S == 11;
+    const size_t slab_h = (s11 ? Lay<Geo<11>>::kSlabH : Lay<Geo<15>>::kSlabH) / 2, half_h = slab_h / 2;      // in fp16 elements
+    const int rowu = s11 ? (int)Geo<11>::ROWU : (int)Geo<15>::ROWU, poff = s11 ? Geo<11>::POFF : Geo<15>::POFF, npix = n->S * n->S;
+    std::vector<_Float16> h((size_t)batch * (C / 32) * slab_h);
     FS_HIP_OK(hipDeviceSynchronize());
     FS_HIP_OK(hipMemcpy(h.data(), bufs[which], h.size() * 2, hipMemcpyDeviceToHost));
     for (int b = 0; b < batch; ++b)
         for (int c = 0; c < C; ++c)
-            for (int p = 0; p < kNPIX; ++p) {
-                const size_t slab = ((size_t)b * (C / 32) + c / 32) * (kSlabB / 2);
-                const size_t idx = slab + ((size_t)((c % 32) / 8) * kPIX + p + kS) * 8 + c % 8;
-                host[((size_t)b * C + c) * kNPIX + p] = (float)h[idx] + (float)h[idx + kHalfB / 2];
+            for (int p = 0; p < npix; ++p) {
+                const size_t slab = ((size_t)b * (C / 32) + c / 32) * slab_h;
+                const size_t idx = slab + ((size_t)((c % 32) / 8) * rowu + p + poff) * 8 + c % 8;
+                host[((size_t)b * C + c) * npix + p] = (float)h[idx] + (float)h[idx + half_h];
             }
     return C;
 }

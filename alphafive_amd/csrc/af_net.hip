@@ -1172,7 +1172,7 @@ int af_net_finalize(af_net* n) {
     n->allocs.clear();
     f16s_destroy(n->f16s);
     n->f16s = nullptr;
-    if (n->S == 11 && f16s_create(&n->f16s, n->max_batch, n->device, n->vars) != 0) return AF_NET_ERR_HIP;
+    if (f16s_supported(n->S) && f16s_create(&n->f16s, n->S, n->max_batch, n->device, n->vars) != 0) return AF_NET_ERR_HIP;
     auto& V = n->vars;
     int rc = AF_NET_OK;
 #define UP(dst, vec) if (!rc) rc = net_upload(n, &n->dst, (vec))
@@ -1295,6 +1295,7 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     float* o[5];
     for (int i = 0; i < 5; ++i) { g[i] = n->g[i] + po * kBlocks[i].cout; o[i] = n->o[i] + po * kBlocks[i].cout; }
     const bool split16 = g_wino == 5 && n->f16s != nullptr;
+    const bool fhead = split16 && g_fhead && S == 11;      // heads fused into the split-operand path (laid out for 11x11)
     if (split16) {
         f16s_set_ablation(n->f16s, g_f16s_abl);
         if (f16s_trunk(n->f16s, st, planes, batch)) return AF_NET_ERR_HIP;
@@ -1317,8 +1318,8 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
         }
         hipStream_t st = (i == 2) ? vs : st_main;
         if (split16) {
-            if (i == 2 && f16s_value_branch(n->f16s, st, batch, o[2], WP, PP, g_fhead ? value : nullptr)) return AF_NET_ERR_HIP;
-            if (i == 4 && f16s_policy_branch(n->f16s, st, batch, o[4], WP, PP, g_fhead ? policy : nullptr)) return AF_NET_ERR_HIP;
+            if (i == 2 && f16s_value_branch(n->f16s, st, batch, o[2], WP, PP, fhead ? value : nullptr)) return AF_NET_ERR_HIP;
+            if (i == 4 && f16s_policy_branch(n->f16s, st, batch, o[4], WP, PP, fhead ? policy : nullptr)) return AF_NET_ERR_HIP;
         } else if (g_wino) {
             // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
             launch_wino(st, n, batch, block_in[i], n->wino1_u[i], n->wino1_ul[i], b.cin, nullptr, nullptr, 0,
@@ -1339,13 +1340,13 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
             launch_conv(st, a);
         }
         if (i == 2) {
-            if (!(split16 && g_fhead))
+            if (!fhead)
             hipLaunchKernelGGL(af_value_head, dim3((batch + VPB - 1) / VPB), dim3(256), 0, st, o[2], n->vc_w, n->vc_b, n->v1_w, n->v1_b,
                                n->v2_w, n->v2_b, value, batch, S, WP, PP);
             if (vs != st_main) NET_HIP_OK(hipEventRecord(n->ev_value, vs));
         }
     }
-    if (split16 && g_fhead) {
+    if (fhead) {
         // (the policy head ran inside f16s_policy_branch)
     } else if (HW <= 128 && g_phead) {
         const int K = 16 * HW, KS = K + ((2 - K % 32) + 32) % 32;

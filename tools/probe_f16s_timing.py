@@ -22,6 +22,7 @@ hn = net_hip.HipNet(net.variables, 11, B, "cuda")
 xb = torch.from_numpy(_positions(11, B, seed=1)).cuda()
 net_hip.tune(0, 5)
 net_hip.tune(4, 0)
+net_hip.tune(7, int(os.environ.get("ABLBITS", 0)))           # af_conv_f16s ablation bits (2 = no stores, 1 = no LDS-DMA after the first slabs)
 for _ in range(3):
     hn(xb)
 torch.cuda.synchronize()
@@ -41,5 +42,7 @@ for li in range(10):
           100 * d[:, 4].sum() / tot))
     w = buf[li].reshape(-1, 4, 9).astype(np.float64)
     w = w[w[:, 0, 6] > 0]
+    print("      cycles per position: items %.0f  vmcnt %.0f  barrier %.0f  exchange %.0f  epilogue %.0f" % tuple(
+        d[:, q].sum() / d[:, 6].sum() for q in (0, 1, 2, 3, 4)))
     print("      per wave: items %s  epilogue %s  exch-barrier %s (cycles per position)" % tuple(
         np.round(w[:, :, q].sum(0) / w[:, :, 6].sum(0)).astype(int).tolist() for q in (0, 4, 7)))

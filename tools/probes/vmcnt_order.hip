@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void probe_load_then_stores(const uint4* __res
 #pragma unroll
         for (int s = 0; s < NST; ++s) {
             const u32x4 v = {(uint32_t)it, (uint32_t)s, (uint32_t)lane, 7u};
-            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(hp + s * 64), "v"(v) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(hp + s * 64), "v"(v) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
         const uint4 got = dst[wv][lane];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void probe_stores_then_load(uint4* __restrict_
             rng = rng * 1664525u + 1013904223u;
             const size_t unit = ((size_t)rng * 64u) % (cold_units - 64);
             const u32x4 v = {(uint32_t)(unit + lane), ~(uint32_t)(unit + lane), 0u, 0u};          // keeps the buffer's pattern intact
-            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(cold + unit + lane), "v"(v) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(cold + unit + lane), "v"(v) : "memory");
         }
         u32x4 v;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(hp) : "memory");
