@@ -81,7 +81,16 @@ template <class G> struct Lds {
     static constexpr uint32_t kBiasOff = kZoff + Lay<G>::kSlotL;         // 128 floats
     static constexpr uint32_t kScrOff = kBiasOff + 512u;                 // k-split exchange
 };
-// (11x11 only: the stem, the fused heads and the dense kernels below)
+// fused head inputs (see "The dense layers of the two heads" below)
+template <class G> struct Hx {
+    static constexpr int HXP = 128 * G::HALVES;
+    static constexpr uint32_t kValPos = HXP * 16u, kValLo = HXP * 8u;       // value: bytes per position / offset of the lo halves
+    static constexpr uint32_t kPolPos = HXP * 64u, kPolLo = HXP * 32u;      // policy
+    static constexpr int VSTEPS = (G::NPIX + 3) / 4;                        // value fc1 k-steps (4 pixels x 4 channels): 31 / 57
+    static constexpr int NLT = (G::NPIX + 31) / 32;                         // policy logit tiles of 32: 4 / 8
+};
+
+// (11x11 only: the MFMA stem below)
 constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;
 constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB;
 
@@ -184,7 +193,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     constexpr uint32_t kRowH = L::kRowH, kHalfH = L::kHalfH, kSlabH = L::kSlabH, kRowL = L::kRowL, kHalfL = L::kHalfL, kSlotL = L::kSlotL;
     constexpr uint32_t kZoff = Lds<G>::kZoff, kBiasOff = Lds<G>::kBiasOff, kScrOff = Lds<G>::kScrOff;
     constexpr int NPC = G::NPC, HV = G::HALVES;
-    static_assert(HD == 0 || G::S == 11, "the fused head inputs are laid out for 11x11");
     constexpr int NT = 4 / PS;                    // pixel tiles per wave
     constexpr int C16 = 2 / KS;                   // 16-channel k-steps per slab and wave
     constexpr int ITP = C16, ITM = 9 * C16;       // items (k-step x tap) per projection / main slab
@@ -596,14 +604,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     if (HD == 1) {
                         if (kg == 0) {
                             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                            char* o = A.hx + (size_t)pos * 2048u + (uint32_t)pix[jj] * 8u;
+                            char* o = A.hx + (size_t)pos * Hx<G>::kValPos + (uint32_t)pix[jj] * 8u;
                             *reinterpret_cast<h4*>(o) = h4{uh[0], uh[1], uh[2], uh[3]};
-                            *reinterpret_cast<h4*>(o + 1024) = h4{ul[0], ul[1], ul[2], ul[3]};
+                            *reinterpret_cast<h4*>(o + Hx<G>::kValLo) = h4{ul[0], ul[1], ul[2], ul[3]};
                         }
                     } else {
-                        char* o = A.hx + (size_t)pos * 8192u + (uint32_t)pix[jj] * 32u + (uint32_t)kg * 16u;
+                        char* o = A.hx + (size_t)pos * Hx<G>::kPolPos + (uint32_t)pix[jj] * 32u + (uint32_t)kg * 16u;
                         *reinterpret_cast<h8*>(o) = h8{uh[0], uh[1], uh[2], uh[3], uh[4], uh[5], uh[6], uh[7]};
-                        *reinterpret_cast<h8*>(o + 4096) = h8{ul[0], ul[1], ul[2], ul[3], ul[4], ul[5], ul[6], ul[7]};
+                        *reinterpret_cast<h8*>(o + Hx<G>::kPolLo) = h8{ul[0], ul[1], ul[2], ul[3], ul[4], ul[5], ul[6], ul[7]};
                     }
                 }
             } else if (OUT32) {
@@ -775,34 +783,37 @@ __global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict
 
 // ----------------------------------------------------------------------------------------------------------------------------
 // The dense layers of the two heads on the same split-operand MFMA (network.py:70-76 value, :82-88 policy).  Their inputs
-// come from the fused 1x1 convolution of the branch's last conv kernel (HD above), already split into halves:
-//   value   xv [position][hi|lo][128 pixels][4 channels]   fp16 (2 KB / position)
-//   policy  xp [position][hi|lo][128 pixels][16 channels]  fp16 (8 KB / position)
+// come from the fused 1x1 convolution of the branch's last conv kernel (HD above), already split into halves
+// (HXP = 128 x HALVES pixel slots per position; the slots past S*S stay zero):
+//   value   xv [position][hi|lo][HXP pixels][4 channels]   fp16 (2 KB / position at 11x11, 4 KB at 15x15)
+//   policy  xp [position][hi|lo][HXP pixels][16 channels]  fp16 (8 KB / 16 KB)
 // and a k-step of 16 is chosen so that 16 contiguous bytes of a position ARE a lane's B operand: value k = 4 pixels x 4
 // channels, policy k = the 16 channels of one pixel.  The dense weights are streamed from L2 as pre-packed A fragments.
 // ----------------------------------------------------------------------------------------------------------------------------
-// value: fc1 484 -> 64 + ELU, fc2 64 -> 1, tanh(x/2).  Workgroup = 32 positions x 2 waves (cout tile mt of 32).  The whole job is
-// 93 MFMAs per wave: what matters is that a wave's operand loads are all in flight at once (two batches of 16 k-steps).
+// value: fc1 4*S*S -> 64 + ELU, fc2 64 -> 1, tanh(x/2).  Workgroup = 32 positions x 2 waves (cout tile mt of 32).  The whole job
+// is 93 (171 at 15x15) MFMAs per wave: what matters is that a wave's operand loads are all in flight at once (batches of 16 k-steps).
+template <class G>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void af_value_fc_f16s(
-    const char* __restrict__ xv, const uint4* __restrict__ a /*[31][2][hi|lo][64]*/, const float* __restrict__ b1, const float* __restrict__ w2,
+    const char* __restrict__ xv, const uint4* __restrict__ a /*[VSTEPS][2][hi|lo][64]*/, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, float inv_scale, float* __restrict__ value, int batch) {
     __shared__ float red[2][32];
+    constexpr int NS = Hx<G>::VSTEPS;
     const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, n = lane & 31, kg = lane >> 5;
     const int pos = (int)blockIdx.x * 32 + n, posc = pos < batch ? pos : batch - 1;
-    const char* xb = xv + (size_t)posc * 2048u + (uint32_t)kg * 16u;
+    const char* xb = xv + (size_t)posc * Hx<G>::kValPos + (uint32_t)kg * 16u;
     const uint4* ap = a + (size_t)mt * 128 + lane;                          // + step * 256 + half * 64
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < (NS + 15) / 16; ++half) {
         uint4 bh[16], bl[16], ah[16], al[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int s_ = 16 * half + q;
-            if (s_ < 31) {
+            if (s_ < NS) {
                 bh[q] = *reinterpret_cast<const uint4*>(xb + s_ * 32);
-                bl[q] = *reinterpret_cast<const uint4*>(xb + 1024 + s_ * 32);
+                bl[q] = *reinterpret_cast<const uint4*>(xb + Hx<G>::kValLo + s_ * 32);
                 ah[q] = ap[(size_t)s_ * 256];
                 al[q] = ap[(size_t)s_ * 256 + 64];
             }
@@ -810,7 +821,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {                          // every load above is issued before the first MFMA waits
-            if (16 * half + q < 31) {
+            if (16 * half + q < NS) {
                 u32x4 t0, t1, t2, t3;
                 __builtin_memcpy(&t0, &bh[q], 16); __builtin_memcpy(&t1, &bl[q], 16); __builtin_memcpy(&t2, &ah[q], 16); __builtin_memcpy(&t3, &al[q], 16);
                 asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            if (16 * half + q < 31) {
+            if (16 * half + q < NS) {
                 h8 xh, xl, wh, wl;
                 __builtin_memcpy(&xh, &bh[q], 16); __builtin_memcpy(&xl, &bl[q], 16);
                 __builtin_memcpy(&wh, &ah[q], 16); __builtin_memcpy(&wl, &al[q], 16);
@@ -841,47 +852,57 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (mt == 0 && kg == 0 && pos < batch) value[pos] = tanhf((red[0][n] + red[1][n] + b2[0]) * 0.5f);
 }
 
-// policy: fc 1936 -> 121, softmax.  Workgroup = 32 positions x 8 waves = (tile of 32 logits) x (half of K): two waves per SIMD, so
-// that one wave's LDS / L2 latency sits under the other's MFMAs (the compiler would not keep the operand fetch of a single wave
-// ahead of its MFMAs: 30 us; a fully unrolled, hand-prefetched single-wave variant was slower still).  The positions' inputs are
-// staged through LDS 16 pixels at a time per K half (transposed to [half][pixel][channel octet][position] rows of 528 bytes:
-// conflict-free ds_read_b128 B fragments), the A fragments ride a 16-step register ring.
+// policy: fc 16*S*S -> S*S, softmax.  Workgroup = 32 positions x 8 waves = (MT tiles of 32 logits: mt, mt + 4, ...) x (half of K):
+// two waves per SIMD, so that one wave's LDS / L2 latency sits under the other's MFMAs (the compiler would not keep the operand
+// fetch of a single wave ahead of its MFMAs: 30 us; a fully unrolled, hand-prefetched single-wave variant was slower still).  The
+// positions' inputs are staged through LDS 16 pixels at a time per K half (transposed to [half][pixel][channel octet][position]
+// rows of 528 bytes: conflict-free ds_read_b128 B fragments), the A fragments ride a register ring of 16 / MT steps.
 constexpr uint32_t kPfRow = 528u, kPfBuf = 64u * kPfRow;
-constexpr uint32_t kPfLds = 4u * kPfBuf;                                    // [K half][double buffer]; later the logits [32][128] floats
-__global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restrict__ xp, const uint4* __restrict__ a /*[121][4][hi|lo][64]*/,
+constexpr uint32_t kPfLds = 4u * kPfBuf;                                    // [K half][double buffer]; later the logits [32][32 NLT] floats
+template <class G>
+__global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restrict__ xp, const uint4* __restrict__ a /*[S*S][NLT][hi|lo][64]*/,
                                                             const float* __restrict__ bf, float inv_scale, float* __restrict__ policy, int batch) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
+    constexpr int NPIX = G::NPIX, HXP = Hx<G>::HXP, NLT = Hx<G>::NLT, MT = NLT / 4, RD = 16 / MT, NCH = HXP / 32, LW = 32 * NLT;
+    static_assert(NLT % 4 == 0 && LW * 32 * 4 <= (int)kPfLds, "logit tiles");
     const int t = threadIdx.x & 255, kh = threadIdx.x >> 8, lane = t & 63, mt = t >> 6, n = lane & 31, kg = lane >> 5;
     const int b0 = (int)blockIdx.x * 32;
     char* const sm = psm + (uint32_t)kh * 2u * kPfBuf;
-    // K half kh = chunks 4 kh .. 4 kh + 3 of 16 pixels (the last one has 9).  Staging of a chunk: unit u = 256 i + t, i = 0..7:
-    // segment u >> 5 = (position, half), 16-byte unit u & 31 = (pixel, octet)
+    // K half kh = chunks NCH kh .. NCH kh + NCH - 1 of 16 pixels (the last ones are partly / wholly past S*S).  Staging of a
+    // chunk: unit u = 256 i + t, i = 0..7: segment u >> 5 = (position, half), 16-byte unit u & 31 = (pixel, octet)
     const char* src[8];
     uint32_t dst[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int u = 256 * i + t, seg = u >> 5, pl = seg >> 1, hl = seg & 1, wi = u & 31, px = wi >> 1, oc = wi & 1;
         const int p = b0 + pl < batch ? b0 + pl : batch - 1;
-        src[i] = xp + (size_t)p * 8192u + (uint32_t)hl * 4096u + (uint32_t)(64 * kh + px) * 32u + (uint32_t)oc * 16u;
+        src[i] = xp + (size_t)p * Hx<G>::kPolPos + (uint32_t)hl * Hx<G>::kPolLo + (uint32_t)((HXP / 2) * kh + px) * 32u + (uint32_t)oc * 16u;
         dst[i] = (uint32_t)((hl * 16 + px) * 2 + oc) * kPfRow + (uint32_t)pl * 16u;
     }
     uint4 stg[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const uint4*>(src[i]);
-    uint4 ring[16][2];
-    const int step0 = 64 * kh, nstep = kh ? 57 : 64;
-    const uint4* ap = a + (size_t)step0 * 512 + (size_t)mt * 128 + lane;     // + step * 512 + half * 64
+    uint4 ring[RD][MT][2];
+    const int step0 = (HXP / 2) * kh, nstep = NPIX - step0 < HXP / 2 ? NPIX - step0 : HXP / 2;
+    const uint4* ap = a + ((size_t)step0 * NLT + mt) * 128 + lane;           // + step * NLT * 128 + (4 m) * 128 + half * 64
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { ring[q][0] = ap[(size_t)q * 512]; ring[q][1] = ap[(size_t)q * 512 + 64]; }
+    for (int q = 0; q < RD; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ring[q][m][0] = ap[((size_t)q * NLT + 4 * m) * 128];
+            ring[q][m][1] = ap[((size_t)q * NLT + 4 * m) * 128 + 64];
+        }
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sm + dst[i]) = stg[i];
-    f32x16 acc;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     __syncthreads();
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const uint32_t cur = (uint32_t)(c & 1) * kPfBuf, nxt = kPfBuf - cur;
-        if (c < 3) {
+        if (c < NCH - 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const uint4*>(src[i] + (size_t)(c + 1) * 512u);
         }
@@ -892,52 +913,63 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
             if (step < nstep) {
                 const h8 bh = *reinterpret_cast<const h8*>(bb + (uint32_t)(2 * q) * kPfRow);
                 const h8 bl = *reinterpret_cast<const h8*>(bb + (uint32_t)(2 * (16 + q)) * kPfRow);
-                h8 ah, al;
-                __builtin_memcpy(&ah, &ring[q][0], 16);
-                __builtin_memcpy(&al, &ring[q][1], 16);
-                if (step + 16 < nstep) { ring[q][0] = ap[(size_t)(step + 16) * 512]; ring[q][1] = ap[(size_t)(step + 16) * 512 + 64]; }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    h8 ah, al;
+                    __builtin_memcpy(&ah, &ring[q % RD][m][0], 16);
+                    __builtin_memcpy(&al, &ring[q % RD][m][1], 16);
+                    if (step + RD < nstep) {
+                        ring[q % RD][m][0] = ap[((size_t)(step + RD) * NLT + 4 * m) * 128];
+                        ring[q % RD][m][1] = ap[((size_t)(step + RD) * NLT + 4 * m) * 128 + 64];
+                    }
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m], 0, 0, 0);
+                }
             }
         }
-        if (c < 3) {
+        if (c < NCH - 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sm + nxt + dst[i]) = stg[i];
         }
         __syncthreads();
     }
-    // the two K halves meet in LDS (the staging buffers are dead): rows of a lane = logits 32 mt + 16 kg + r
-    float* Lg = reinterpret_cast<float*>(psm);                               // [32 positions][128]
+    // the two K halves meet in LDS (the staging buffers are dead): rows of a lane = logits 32 (mt + 4 m) + 16 kg + r
+    float* Lg = reinterpret_cast<float*>(psm);                               // [32 positions][LW]
     if (kh == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Lg[n * 128 + 32 * mt + 16 * kg + r] = acc[r];
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Lg[n * LW + 32 * (mt + 4 * m) + 16 * kg + r] = acc[m][r];
     }
     __syncthreads();
     if (kh == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = 32 * mt + 16 * kg + r;
-            Lg[n * 128 + j] = j < kNPIX ? (acc[r] + Lg[n * 128 + j]) * inv_scale + bf[j] : -3.0e38f;
-        }
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * (mt + 4 * m) + 16 * kg + r;
+                Lg[n * LW + j] = j < NPIX ? (acc[m][r] + Lg[n * LW + j]) * inv_scale + bf[j] : -3.0e38f;
+            }
     }
     __syncthreads();
-    const int p = (int)threadIdx.x >> 4, sub = (int)threadIdx.x & 15;        // 16 threads per position, 8 logits each
-    float v[8], m = -3.0e38f;
+    const int p = (int)threadIdx.x >> 4, sub = (int)threadIdx.x & 15;        // 16 threads per position, LW / 16 logits each
+    constexpr int NV = LW / 16;
+    float v[NV], mx = -3.0e38f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { v[q] = Lg[p * 128 + sub + 16 * q]; m = fmaxf(m, v[q]); }
+    for (int q = 0; q < NV; ++q) { v[q] = Lg[p * LW + sub + 16 * q]; mx = fmaxf(mx, v[q]); }
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     float sum = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { v[q] = (sub + 16 * q) < kNPIX ? expf(v[q] - m) : 0.0f; sum += v[q]; }
+    for (int q = 0; q < NV; ++q) { v[q] = (sub + 16 * q) < NPIX ? expf(v[q] - mx) : 0.0f; sum += v[q]; }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
     if (b0 + p < batch) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NV; ++q) {
             const int j = sub + 16 * q;
-            if (j < kNPIX) policy[(size_t)(b0 + p) * kNPIX + j] = v[q] / sum;
+            if (j < NPIX) policy[(size_t)(b0 + p) * NPIX + j] = v[q] / sum;
         }
     }
 }
@@ -1168,7 +1200,8 @@ int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const
         rc = act(&n->g[b], kLayers[2 * b].cout);
         if (!rc && b != 2 && b != 4) rc = act(&n->o[b], kLayers[2 * b + 1].cout);
     }
-    if (!rc && s11) {   // heads: value/conv [32][4], value/fc1 [4*121][64], value/fc2 [64][1]; policy/conv [32][16], policy/fc [16*121][121]
+    if (!rc) {          // heads: value/conv [32][4], value/fc1 [4*S*S][64], value/fc2 [64][1]; policy/conv [32][16], policy/fc [16*S*S][S*S]
+        const int npix = board_size * board_size, hxp = 128 * halves, vsteps = (npix + 3) / 4, nlt = (npix + 31) / 32;
         const char* cname[2] = {"value/conv", "policy/conv"};
         const int nco[2] = {4, 16};
         for (int h = 0; h < 2 && !rc; ++h) {
@@ -1186,15 +1219,15 @@ int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const
             if (!rc) rc = dev_upload(n->allocs, &n->hcb[h], bpad.data(), 64);
             n->hc_inv[h] = 1.0f / sc;
             void* q = nullptr;
-            const size_t bytes = (size_t)max_batch * (h == 0 ? 2048 : 8192);
-            if (!rc) { FS_HIP_OK(hipMalloc(&q, bytes)); FS_HIP_OK(hipMemset(q, 0, bytes)); n->allocs.push_back(q); n->hx[h] = (char*)q; }   // pixels 121..127 stay zero
+            const size_t bytes = (size_t)max_batch * hxp * (h == 0 ? 16 : 64);
+            if (!rc) { FS_HIP_OK(hipMalloc(&q, bytes)); FS_HIP_OK(hipMemset(q, 0, bytes)); n->allocs.push_back(q); n->hx[h] = (char*)q; }   // the pixel slots past S*S stay zero
         }
         if (!rc) {
             const std::vector<float>& w1 = get("value/fc1/kernel");
             const float sc = pick_scale(w1, nullptr);
-            const std::vector<_Float16> pk = pack_frags(31 * 2, [&](int f, int lane, int e) -> float {
+            const std::vector<_Float16> pk = pack_frags(vsteps * 2, [&](int f, int lane, int e) -> float {
                 const int s_ = f >> 1, mt = f & 1, px = 4 * s_ + 2 * (lane >> 5) + (e >> 2), ch = e & 3, j = 32 * mt + row_perm(lane & 31);
-                return px < kNPIX ? w1[(size_t)(ch * kNPIX + px) * 64 + j] * sc : 0.0f;
+                return px < npix ? w1[(size_t)(ch * npix + px) * 64 + j] * sc : 0.0f;
             });
             rc = dev_upload(n->allocs, &n->hfw[0], pk.data(), pk.size() * 2);
             n->hf_inv[0] = 1.0f / sc;
@@ -1205,15 +1238,16 @@ int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const
         if (!rc) {
             const std::vector<float>& wf = get("policy/fc/kernel");
             const float sc = pick_scale(wf, nullptr);
-            const std::vector<_Float16> pk = pack_frags(kNPIX * 4, [&](int f, int lane, int e) -> float {
-                const int px = f >> 2, mt = f & 3, c16 = 8 * (lane >> 5) + e, j = 32 * mt + row_perm(lane & 31);
-                return j < kNPIX ? wf[(size_t)(c16 * kNPIX + px) * kNPIX + j] * sc : 0.0f;
+            const std::vector<_Float16> pk = pack_frags(npix * nlt, [&](int f, int lane, int e) -> float {
+                const int px = f / nlt, mt = f % nlt, c16 = 8 * (lane >> 5) + e, j = 32 * mt + row_perm(lane & 31);
+                return j < npix ? wf[(size_t)(c16 * npix + px) * npix + j] * sc : 0.0f;
             });
             rc = dev_upload(n->allocs, &n->hfw[1], pk.data(), pk.size() * 2);
             n->hf_inv[1] = 1.0f / sc;
-            if (!rc) rc = dev_upload(n->allocs, &n->hfb[1], get("policy/fc/bias").data(), kNPIX * 4);
+            if (!rc) rc = dev_upload(n->allocs, &n->hfb[1], get("policy/fc/bias").data(), npix * 4);
         }
-        if (!rc) FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_policy_fc_f16s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPfLds));
+        if (!rc) FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_policy_fc_f16s<Geo<11>>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPfLds));
+        if (!rc) FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_policy_fc_f16s<Geo<15>>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPfLds));
     }
     if (rc) { f16s_destroy(n); return rc; }
     *out = n;
@@ -1239,15 +1273,13 @@ static int launch_layer_g(f16s_net* n, hipStream_t st, int li, const F16sArgs& a
         case 2: return launch_cfg<G, 2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
         case 3: return launch_cfg<G, 4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
         case 4: return launch_cfg<G, 4, 0, 1, 2, 2, false, false, 1>(st, a, 1, n->ncu);   // (no XACC: weights + projection weights + 3 accumulator sets would spill)
-        case 5:
-            if constexpr (G::S == 11) { if (head == 0) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 1>(st, a, 1, n->ncu); }
-            return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);         // (one pixel tile per wave, whole K: no k-split exchange)
+        case 5: return head == 0 ? launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 1>(st, a, 1, n->ncu)
+                                 : launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);   // (one pixel tile per wave, whole K: no k-split exchange)
         case 6: return launch_cfg<G, 4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
         case 7: return launch_cfg<G, 2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
         case 8: return launch_cfg<G, 2, 0, 1, 1, 4, false, true, 1>(st, a, 1, n->ncu);
-        default:
-            if constexpr (G::S == 11) { if (head == 1) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 2>(st, a, 1, n->ncu); }
-            return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
+        default: return head == 1 ? launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 2>(st, a, 1, n->ncu)
+                                  : launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
     }
 }
 
@@ -1259,7 +1291,7 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
     a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xff) | (li << 8);
     a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
-    return n->S == 11 ? launch_layer_g<Geo<11>>(n, st, li, a, head) : launch_layer_g<Geo<15>>(n, st, li, a, -1);
+    return n->S == 11 ? launch_layer_g<Geo<11>>(n, st, li, a, head) : launch_layer_g<Geo<15>>(n, st, li, a, head);
 }
 
 int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes, int batch) {
@@ -1281,9 +1313,14 @@ int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes, int batch) {
 int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3, int WP, int PP, float* value) {
     int rc = launch_layer(n, st, 4, n->o[1], nullptr, n->g[2], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 5, n->g[2], n->o[1], nullptr, o3, batch, WP, PP, value ? 0 : -1);
-    if (!rc && value)
-        hipLaunchKernelGGL(af_value_fc_f16s, dim3((batch + 31) / 32), dim3(128), 0, st, n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b,
-                           n->hf_inv[0], value, batch);
+    if (!rc && value) {
+        if (n->S == 11)
+            hipLaunchKernelGGL(af_value_fc_f16s<Geo<11>>, dim3((batch + 31) / 32), dim3(128), 0, st, n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b,
+                               n->hf_inv[0], value, batch);
+        else
+            hipLaunchKernelGGL(af_value_fc_f16s<Geo<15>>, dim3((batch + 31) / 32), dim3(128), 0, st, n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b,
+                               n->hf_inv[0], value, batch);
+    }
     return rc;
 }
 
@@ -1292,9 +1329,14 @@ int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP
     if (!rc) rc = launch_layer(n, st, 7, n->g[3], n->o[1], n->o[3], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 8, n->o[3], nullptr, n->g[4], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 9, n->g[4], n->o[3], nullptr, o5, batch, WP, PP, policy ? 1 : -1);
-    if (!rc && policy)
-        hipLaunchKernelGGL(af_policy_fc_f16s, dim3((batch + 31) / 32), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
-                           n->hf_inv[1], policy, batch);
+    if (!rc && policy) {
+        if (n->S == 11)
+            hipLaunchKernelGGL(af_policy_fc_f16s<Geo<11>>, dim3((batch + 31) / 32), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
+                               n->hf_inv[1], policy, batch);
+        else
+            hipLaunchKernelGGL(af_policy_fc_f16s<Geo<15>>, dim3((batch + 31) / 32), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
+                               n->hf_inv[1], policy, batch);
+    }
     return rc;
 }
 

@@ -1295,7 +1295,7 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     float* o[5];
     for (int i = 0; i < 5; ++i) { g[i] = n->g[i] + po * kBlocks[i].cout; o[i] = n->o[i] + po * kBlocks[i].cout; }
     const bool split16 = g_wino == 5 && n->f16s != nullptr;
-    const bool fhead = split16 && g_fhead && S == 11;      // heads fused into the split-operand path (laid out for 11x11)
+    const bool fhead = split16 && g_fhead;                 // heads fused into the split-operand path
     if (split16) {
         f16s_set_ablation(n->f16s, g_f16s_abl);
         if (f16s_trunk(n->f16s, st, planes, batch)) return AF_NET_ERR_HIP;

@@ -134,6 +134,15 @@ _SPLIT_BYTES_PER_POSITION = (30 * 16384 + 19 * 15488 + 2 * 2 * 16384 + 2 * (4 + 
 
 
 def roofline_info(board_size=11):
+    if board_size == 15:
+        # the same kernels on two half-board pseudo-positions per board (8 pixel tiles of 32 for 225 pixels): MFMA work per
+        # position = 256 / 121 of the 11x11 figure; HBM slabs are 32 KB (reads: 2 x 20 KB windows, writes 2 x 15.5 / 12.4 KB)
+        return {"backend": "hip (af_conv_f16s.hip on 15x15: two half-board pseudo-positions per board, fp16 split operands, fp32 "
+                           "accumulation; VALU stem; heads fused like 11x11)",
+                "kernel": "af_net_forward = af_stem_f16s + 10x af_conv_f16s<Geo<15>> + af_value_fc_f16s + af_policy_fc_f16s (whole "
+                          "forward timed)",
+                "peak_tflops": 2500.0, "issued_flop_per_position": 2 * 3 * _SPLIT_MAC_PER_PIXEL * 256,
+                "algorithmic_bytes_per_position": (30 * 2 * 20480 + 19 * 30720 + 2 * 2 * 2 * 16384 + 2 * (4 + 16) * 225 * 2 * 2 + 3 * 225 * 4 + 226 * 4)}
     if board_size == 11:
         return {"backend": "hip (af_conv_f16s.hip: stem, convs and heads on v_mfma_f32_32x32x16_f16 with fp16 split operands and "
                            "fp32 accumulation; convs weight-stationary with an LDS-DMA slab ring)",
