@@ -27,6 +27,9 @@ struct af_replay {
     int sel_cap = 0;
     void* pinned = nullptr;      // staging for append / sample arguments
     size_t pinned_bytes = 0;
+    float* wtab = nullptr;       // [max_T + 1][max_T] construct_weights rows (af_replay_set_weights)
+    int max_T = 0;
+    int32_t* err = nullptr;      // device flag: a packed append whose T did not match the buffer
 };
 
 struct SampleArgs {
@@ -84,6 +87,51 @@ __global__ __launch_bounds__(256) void af_replay_sample_kernel(SampleArgs A) {
     }
 }
 
+// One workgroup per ply of episode `ep` of a packed hand-off buffer (layout: include/af_engine.h af_engine_pack_episodes:
+// header {episodes, plies, K, C}, meta [max_eps][4] = {game, seq, T, first ply}, final values [max_eps], then per ply
+// K u64 key words (mine bitboard, theirs bitboard) | C policy floats | C visit counts | last cell | action).
+struct PackedArgs {
+    const int32_t* buf;
+    int8_t* boards;
+    float* policies;
+    int32_t* last;
+    float* values;
+    float* weights;
+    const float* wtab;
+    int32_t* err;
+    int64_t slot0;               // ring slot of ply 0
+    int cap, C, max_eps, ep, T, max_T;
+};
+
+__global__ __launch_bounds__(256) void af_replay_append_packed_kernel(PackedArgs A) {
+    const int32_t* buf = A.buf;
+    const int n_eps = buf[0], K = buf[2], Cc = buf[3];
+    const int32_t* meta = buf + 4 + 4 * A.ep;
+    const int T = meta[2], p0 = meta[3];
+    if (A.ep >= n_eps || T != A.T || Cc != A.C) {                 // the host's view of the buffer is stale: append nothing
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicExch(A.err, 1);
+        return;
+    }
+    const int t = blockIdx.x, R = 2 * K + 2 * Cc + 2, KW = K / 2;
+    const int32_t* rec = buf + 4 + 5 * A.max_eps + (size_t)(p0 + t) * R;
+    const int64_t slot = (A.slot0 + t) % A.cap;
+    const uint32_t* key = reinterpret_cast<const uint32_t*>(rec);      // u64 word w = key[2w] | key[2w+1] << 32
+    for (int c = threadIdx.x; c < Cc; c += blockDim.x) {
+        const int w = c >> 6, b = c & 63;
+        const uint32_t mine = key[2 * w + (b >> 5)] >> (b & 31), theirs = key[2 * (KW + w) + (b >> 5)] >> (b & 31);
+        A.boards[slot * Cc + c] = (int8_t)((mine & 1u) ? 1 : ((theirs & 1u) ? -1 : 0));
+        A.policies[slot * Cc + c] = __int_as_float(rec[2 * K + c]);
+    }
+    if (threadIdx.x == 0) {
+        const float fv = __int_as_float(buf[4 + 4 * A.max_eps + A.ep]);
+        float v = (T & 1) ? -fv : fv;                               // player.py:74-76, then the sign alternates ply by ply (:80-81)
+        if (t & 1) v = -v;
+        A.last[slot] = rec[2 * K + 2 * Cc];
+        A.values[slot] = v;
+        A.weights[slot] = A.wtab[(size_t)T * A.max_T + t];
+    }
+}
+
 static int ensure_pinned(af_replay* r, size_t bytes) {
     if (bytes <= r->pinned_bytes) return AF_REPLAY_OK;
     if (r->pinned) (void)hipHostFree(r->pinned);
@@ -131,6 +179,8 @@ void af_replay_destroy(af_replay* r) {
     if (r->values) (void)hipFree(r->values);
     if (r->weights) (void)hipFree(r->weights);
     if (r->sel) (void)hipFree(r->sel);
+    if (r->wtab) (void)hipFree(r->wtab);
+    if (r->err) (void)hipFree(r->err);
     if (r->pinned) (void)hipHostFree(r->pinned);
     delete r;
 }
@@ -167,6 +217,50 @@ int af_replay_append(af_replay* r, void* stream, int32_t n, const int8_t* boards
     }
     RP_HIP_OK(hipStreamSynchronize(st));               // pageable host memory: the caller may reuse its arrays on return
     r->count += n;
+    return AF_REPLAY_OK;
+}
+
+int af_replay_set_weights(af_replay* r, const float* table_host, int32_t max_T) {
+    if (!r || !table_host || max_T < 1) return AF_REPLAY_ERR_ARG;
+    RP_HIP_OK(hipSetDevice(r->device));
+    RP_HIP_OK(hipDeviceSynchronize());                 // no append may still be reading the old table
+    if (r->wtab) (void)hipFree(r->wtab);
+    r->wtab = nullptr; r->max_T = 0;
+    const size_t bytes = (size_t)(max_T + 1) * max_T * 4;
+    RP_HIP_OK(hipMalloc(reinterpret_cast<void**>(&r->wtab), bytes));
+    RP_HIP_OK(hipMemcpy(r->wtab, table_host, bytes, hipMemcpyHostToDevice));
+    if (!r->err) {
+        RP_HIP_OK(hipMalloc(reinterpret_cast<void**>(&r->err), 4));
+        RP_HIP_OK(hipMemset(r->err, 0, 4));
+    }
+    r->max_T = max_T;
+    return AF_REPLAY_OK;
+}
+
+int af_replay_append_packed(af_replay* r, void* stream, const int32_t* packed_dev, int32_t max_episodes, int32_t episode, int32_t T) {
+    if (!r || !packed_dev || max_episodes < 1 || episode < 0 || episode >= max_episodes || T < 1) return AF_REPLAY_ERR_ARG;
+    if (!r->wtab || T > r->max_T) return AF_REPLAY_ERR_ARG;      // af_replay_set_weights first
+    if (r->count + T > r->cap) return AF_REPLAY_ERR_FULL;
+    RP_HIP_OK(hipSetDevice(r->device));
+    PackedArgs a;
+    a.buf = packed_dev; a.boards = r->boards; a.policies = r->policies; a.last = r->last; a.values = r->values; a.weights = r->weights;
+    a.wtab = r->wtab; a.err = r->err; a.slot0 = (r->head + r->count) % r->cap; a.cap = r->cap; a.C = r->C;
+    a.max_eps = max_episodes; a.ep = episode; a.T = T; a.max_T = r->max_T;
+    hipLaunchKernelGGL(af_replay_append_packed_kernel, dim3(T), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    RP_HIP_OK(hipGetLastError());
+    r->count += T;
+    return AF_REPLAY_OK;
+}
+
+/* 1 if a packed append found the buffer not to hold what the host said (and appended nothing); clears the flag */
+int af_replay_check(af_replay* r, void* stream) {
+    if (!r) return AF_REPLAY_ERR_ARG;
+    if (!r->err) return 0;
+    int32_t h = 0;
+    RP_HIP_OK(hipSetDevice(r->device));
+    RP_HIP_OK(hipMemcpyAsync(&h, r->err, 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    RP_HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (h) { RP_HIP_OK(hipMemset(r->err, 0, 4)); return AF_REPLAY_ERR_RANGE; }
     return AF_REPLAY_OK;
 }
 

@@ -99,11 +99,16 @@ def train_loop(config, engine, net, stack, trainer, steps, log=print):
     """main.py:57-76 with the five gen_data processes replaced by the device batch `engine`
     (alphafive_amd.engine.SelfPlayEngine): every accepted episode triggers 4 minibatches once the buffer is full."""
     step = 1
+    on_device = hasattr(stack, "iter_push_packed") and hasattr(engine, "post_episodes_device")
+    cap = 256
     while step < steps:
         engine.run_ticks(256)
         engine.check()
-        for data_record, result in engine.pop_episodes():
-            r = stack.push(data_record, result)         # every popped episode reaches the buffer, also after the last step
+        if on_device:       # episodes never leave the GPU: packed by the engine, decoded into the replay ring by one launch each
+            pushes = stack.iter_push_packed(engine.post_episodes_device(cap), cap, config.gamma)
+        else:
+            pushes = (stack.push(data_record, result) for data_record, result in engine.pop_episodes())
+        for r in pushes:                                # every finished episode reaches the buffer, also after the last step
             if r and stack.is_full() and step < steps:
                 for _ in range(4):
                     boards, weights, values, policies = stack.get_data(batch_size=config.batch_size)

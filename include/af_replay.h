@@ -41,6 +41,23 @@ void af_replay_destroy(af_replay* r);
  * policies float32[n][C], last_cell int32[n] (i*S+j, or -1 for None), values float32[n], weights float32[n]. */
 int af_replay_append(af_replay* r, void* stream, int32_t n, const int8_t* boards, const float* policies,
                      const int32_t* last_cell, const float* values, const float* weights);
+/* Device-to-device append ("keep episodes on-GPU for the trainer"): episode `episode` of a packed hand-off buffer
+ * that af_engine_pack_episodes (include/af_engine.h) wrote into DEVICE memory with the same max_episodes.  One launch on `stream`
+ * decodes every ply of it on the device — position key -> board int8 (+1 mine / -1 theirs: utils.py:185 state_to_board of the
+ * recorded root), temperature policy, last move, value = the final value with the signs of player.py:74-82, weight = row T of the
+ * table below — straight into the ring.  `T` (the episode's length, which the host reads from the buffer's small header for
+ * RandomStack.push's bookkeeping anyway) sizes the launch and must equal the length recorded in the buffer (checked on the
+ * device: a mismatch appends nothing and raises the flag af_replay_check() reports).  No host copy of the
+ * episode, no per-ply host work. */
+int af_replay_append_packed(af_replay* r, void* stream, const int32_t* packed_dev, int32_t max_episodes, int32_t episode, int32_t T);
+/* The per-ply training weights utils.construct_weights(T, gamma) (utils.py:286-296; numpy float32 arithmetic) for every episode
+ * length: table[max_T + 1][max_T] float32, row T holds w[0..T-1].  Computed by the host mirror (the numpy restatement is the
+ * spec: pairwise float32 sum), uploaded once per gamma. */
+int af_replay_set_weights(af_replay* r, const float* table_host, int32_t max_T);
+/* AF_REPLAY_ERR_RANGE if a packed append since the last call found the buffer not to hold the episode the host described (it
+ * appended nothing then); synchronises `stream`.  AF_REPLAY_OK otherwise. */
+int af_replay_check(af_replay* r, void* stream);
+
 /* Forget the n oldest positions (utils.py:103 `del self.data[:beyond]`). */
 int af_replay_drop_front(af_replay* r, int32_t n);
 int32_t af_replay_size(const af_replay* r);

@@ -158,3 +158,52 @@ def test_closed_loop_self_play_replay_train_on_device(capsys):
     assert (p_hip - p_t).abs().max().item() < 1e-5                                 # ... and the HIP evaluator has them
     sp.close()
     stack.close()
+
+
+@pytest.mark.parametrize("S, goal, sims, G, length", [(6, 4, 24, 48, 400), (11, 5, 12, 32, 900)])
+def test_device_to_device_hand_off_equals_the_host_path(S, goal, sims, G, length, capsys):
+    """SURVEY 8f-1 / main.py:60-61: finished episodes go from the engine's pack kernels straight into the device replay ring
+    (af_replay_append_packed: key -> board, policy, last move, value signs, construct_weights row) — the host reads only the
+    header.  Same seeds => the same accept / duplicate / evict decisions and bit-identical batches as pushing the 5-tuples of
+    a twin engine into the host RandomStack."""
+    import torch
+    import pseudonet
+    from conftest import make_cfg
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.replay import DeviceRandomStack
+    cfg = make_cfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=sims + 8)
+    mk = lambda: SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, 321, 4096), device=0, seed=13)
+    a, b = mk(), mk()
+    host, dev = utils.RandomStack(S, length), DeviceRandomStack(S, length, device=0)
+    logs = []
+    for which, sp, st in (("host", a, host), ("dev", b, dev)):
+        random.seed(5)
+        np.random.seed(5)
+        log = []
+        for rnd in range(14):
+            sp.run_ticks(120)
+            sp.check()
+            if which == "host":
+                log += [st.push(rec, res) for rec, res in sp.pop_episodes(64)]
+            else:
+                log += st.push_packed(sp.post_episodes_device(64), 64, cfg.gamma)
+            if st._size() >= 32:
+                log.append([np.asarray(t.cpu() if torch.is_tensor(t) else t) for t in st.get_data(48)])
+        log.append((st.black_win, st.white_win, list(st.data_len), list(st.result), st._size()))
+        logs.append(log)
+    dev.check()
+    capsys.readouterr()
+    h, d = logs
+    assert len(h) == len(d) and sum(1 for x in h if x is True) > 10
+    nb = 0
+    for x, y in zip(h, d):
+        if isinstance(x, list):
+            nb += 1
+            for u, v in zip(x, y):
+                assert u.shape == v.shape and u.dtype == v.dtype and np.array_equal(u.view(np.uint32), v.view(np.uint32))
+        else:
+            assert x == y
+    assert nb >= 3 and h[-1][4] <= length and any(isinstance(x, bool) and not x for x in h)     # rejections and eviction happened
+    a.close()
+    b.close()
+    dev.close()
