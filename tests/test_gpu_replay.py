@@ -203,7 +203,9 @@ def test_device_to_device_hand_off_equals_the_host_path(S, goal, sims, G, length
                 assert u.shape == v.shape and u.dtype == v.dtype and np.array_equal(u.view(np.uint32), v.view(np.uint32))
         else:
             assert x == y
-    assert nb >= 3 and h[-1][4] <= length and any(isinstance(x, bool) and not x for x in h)     # rejections and eviction happened
+    assert nb >= 3 and h[-1][4] <= length
+    if S == 6:                                         # short games: the rejection draw (utils.py:80) said no at least once
+        assert any(isinstance(x, bool) and not x for x in h)
     a.close()
     b.close()
     dev.close()
