@@ -107,6 +107,28 @@ def test_player_device_graph_path_matches_oracle_at_the_metric_settings(training
     pl.close()
 
 
+def test_player_device_graph_path_on_15x15_matches_oracle():
+    """BASELINE configs[3]'s board: the same device / HIP-graph Player path on 15x15 (4-word bitboards; the net's split-operand
+    kernels run two half-board pseudo-positions per board), random-init weights, against the oracle fed by a second handle."""
+    from alphafive_amd.network import ResNet
+    from alphafive_amd.player import Player
+    from test_gpu_parity import _compare_tree
+    import torch
+    net = ResNet(15, device="cuda", seed=21)
+    opv = net.select_backend("hip")
+
+    def eval_np(x):
+        p, v = opv(torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda())
+        return p.cpu().numpy().copy(), v.cpu().numpy().copy()
+    cfg = make_cfg(board_size=15, simulation_per_step=200, upper_simulation_per_step=260)
+    pl = Player(cfg, training=True, pv_fn=net.eval, seed=4, game_id=9)
+    orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=4, game_id=9, pv_fn=eval_np)
+    _drive(pl, orc, True, 4, S=15)
+    assert pl.backend == "hip" and pl._graph is not None and pl._graph[1] is not None
+    _compare_tree(pl._engine.tree_dump(0), orc, 15)
+    pl.close()
+
+
 def test_player_graph_path_follows_a_weight_update():
     """choose_best_player.py:78-82 reloads the nets between matches while the Players live on: a replayed graph skips the
     Python wrapper that notices net.restore()/load_npz()/set_variables(), so the graph is keyed on the weight version.
