@@ -478,14 +478,17 @@ def main():
         # committed counter profile of THIS round's kernels when this run is the profiled workload, else null
         traffic_net = traffic_tick = None
         traffic_src = None
-        tp = os.path.join(REPO, "profiles", "r2_pmc_hbm_traffic.json")
+        tp = os.path.join(REPO, "profiles", "r3_pmc_hbm_traffic.json")
+        if not os.path.exists(tp):
+            tp = os.path.join(REPO, "profiles", "r2_pmc_hbm_traffic.json")
+        tp_name = "profiles/" + os.path.basename(tp)
         if os.path.exists(tp) and deep is None and roof["backend"].startswith("hip"):
             with open(tp) as f:
                 prof = json.load(f)
             if prof["workload"] == {"games": G, "board_size": cfg.board_size}:
                 traffic_net = prof["net_forward_bytes_per_launch"]["corrected"]
                 traffic_tick = prof["tick_kernel_bytes_per_launch"]["corrected"]
-                traffic_src = "profiles/r2_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                traffic_src = tp_name + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
                 # ... and, unless --no-pmc, collected again in THIS run: two short rocprofv3 counter passes over the same kernels
                 # (child processes, after the timed region; the net's traffic does not depend on the game phase, the tick
                 # kernel's does, so tree_roofline keeps the steady-state figure of the file)
@@ -494,8 +497,8 @@ def main():
                     traffic_net = live
                     traffic_src = ("this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
                                    "tools/probe_tick_min.py, bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the forward's "
-                                   "kernels, mean of the last 200 dispatches; profiles/r2_pmc_hbm_traffic.json has %.3f GB"
-                                   % (prof["net_forward_bytes_per_launch"]["corrected"] / 1e9))
+                                   "kernels, mean of the last 200 dispatches; %s has %.3f GB"
+                                   % (tp_name, prof["net_forward_bytes_per_launch"]["corrected"] / 1e9))
         if deep is not None:
             roof = ({"backend": "torch-rocm bf16 (MIOpen/hipBLASLt), 8 residual blocks x 128",
                      "kernel": "deep net forward (PyTorch-ROCm ops, whole forward timed)"} if args.net.endswith("torch") else
