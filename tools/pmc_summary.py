@@ -12,7 +12,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for k, c, v, d in rows:
     if flt in k: acc[k][c].append(v)
 for k in acc:
-    print(k[:90])
+    print(k[:200])
     for c, vs in sorted(acc[k].items()):
         total = len(vs)
         vs = vs[-last:] if last else vs

@@ -13,10 +13,22 @@ dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "r3_p
 
 
 def short(name):
+    """kernel name without namespaces and argument list, template arguments kept (balanced brackets)"""
     name = re.sub(r"\(anonymous namespace\)::", "", name.strip())
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"([A-Za-z_0-9]+(<[^>]*>)?)", name)
-    return m.group(1) if m else name
+    m = re.match(r"[A-Za-z_0-9]+", name)
+    if not m:
+        return name
+    out, i = m.group(0), m.end()
+    if i < len(name) and name[i] == "<":
+        depth = 0
+        for j in range(i, len(name)):
+            depth += name[j] == "<"
+            depth -= name[j] == ">"
+            if depth == 0:
+                return out + name[i:j + 1].replace(" >", ">")
+        return out + name[i:]                     # (truncated by the producer of the text file)
+    return out
 
 
 kern, passes, cur = {}, [], None
