@@ -99,7 +99,8 @@ constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB
 //   AF_F16S_MAIN_FIRST 1: a position's 3x3 slabs stream before the slabs of the folded 1x1 projection: 1.357 -> 1.352 ms, and
 //                         |dv| 1.5e-6 -> 8.7e-7 (the small projection terms are added last)
 //   AF_F16S_NT_STORE   1: nt hint on the activation stores: no gain (1.421 vs 1.421)
-// Tried and removed (r3): leaving the epilogue's stores in flight across the next position's first LDS-DMA waits (vmcnt counts
+// Tried and removed (r3): the lo halves of the split by v_fma_mixlo/mixhi_f16 (one instruction per element instead of convert back,
+// subtract, convert): same bits, 1.433 vs 1.436 ms (profiles/r3_15).  Leaving the epilogue's stores in flight across the next position's first LDS-DMA waits (vmcnt counts
 // stores too and a wave's operations retire in issue order — tools/probes/vmcnt_order.hip — so the counts can be relaxed by the
 // number of younger stores): correct, 1.421 vs 1.421 ms — the waits do not sit on store acknowledgements; the epilogue is
 // VALU-bound (profiles/r3_07).  Stores issued by hand in an asm block: corrupt activations (a hazard the compiler cannot see).
@@ -112,29 +113,6 @@ constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB
 #ifndef AF_F16S_MAIN_FIRST
 #define AF_F16S_MAIN_FIRST 1
 #endif
-
-//   AF_F16S_MIXLO      1: the lo halves of the activation split by v_fma_mixlo/mixhi_f16 (lo = f16(f - hi) in one instruction per
-//                         element, reading hi as an f16 operand: no v_cvt_f32_f16 + subtract + v_cvt_pk); same bits (f - hi is
-//                         exact in fp32)
-#ifndef AF_F16S_MIXLO
-#define AF_F16S_MIXLO 0
-#endif
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-// f[0..7] -> hi = f16(f) (RNE), lo = f16(f - hi)
-__device__ __forceinline__ void split8(const float* f, h8& hi, h8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const h2v hp = {(_Float16)f[e], (_Float16)f[e + 1]};
-        uint32_t hpb, lob;
-        __builtin_memcpy(&hpb, &hp, 4);
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-            : "=&v"(lob) : "v"(hpb), "v"(f[e]), "v"(f[e + 1]));
-        h2v lp;
-        __builtin_memcpy(&lp, &lob, 4);
-        hi[e] = hp[0]; hi[e + 1] = hp[1];
-        lo[e] = lp[0]; lo[e + 1] = lp[1];
-    }
-}
 
 __device__ __forceinline__ void st16(void* gdst, const h8& v) {
 #if AF_F16S_NT_STORE
@@ -649,9 +627,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     h8 hi, lo;
-#if AF_F16S_MIXLO
-                    split8(&v[8 * hf], hi, lo);
-#else
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float f = v[8 * hf + e];
@@ -659,7 +634,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                         hi[e] = h;
                         lo[e] = (_Float16)(f - (float)h);
                     }
-#endif
                     if (ok[jj] && !(A.abl & 2)) {             // (tile 3 always has valid lanes: the two stores are always issued)
                         st16(o + hf * kRowH, hi);
                         st16(o + hf * kRowH + kHalfH, lo);
