@@ -113,6 +113,13 @@ constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB
 #ifndef AF_F16S_MAIN_FIRST
 #define AF_F16S_MAIN_FIRST 1
 #endif
+//   AF_F16S_ZPAD       1: the lanes of a pixel tile that lie past the board (7 of 128 at 11x11, 31 of 128 in the second half of
+//                         a 15x15 board) read their B fragments from the all-zero LDS region instead of a real pixel's: the
+//                         results of those columns are discarded either way, but zero operands toggle fewer MFMA bits and the
+//                         chip's clock is power-bound under this load (MI355X_MICROARCH.md, DVFS)
+#ifndef AF_F16S_ZPAD
+#define AF_F16S_ZPAD 1
+#endif
 
 __device__ __forceinline__ void st16(void* gdst, const h8& v) {
 #if AF_F16S_NT_STORE
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     h8 fr[2][NT][2];
 #define AF_FIRST_ITEM(slot)                                                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                          \
-        const uint32_t c_ = lb[jj] + (slot), l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_;         \
+        const uint32_t c_ = (AF_F16S_ZPAD && !ok[jj]) ? zb[jj] : lb[jj] + (slot), l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_; \
         fr[0][jj][0] = rd(smem, NSP > 0 && !AF_F16S_MAIN_FIRST, 0, 0, c_, l_, r_);                               \
         fr[0][jj][1] = rd(smem, NSP > 0 && !AF_F16S_MAIN_FIRST, 0, 1, c_, l_, r_);                               \
     }
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             uint32_t bC[NT], bL[NT], bR[NT];
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
-                bC[jj] = lb[jj] + cur;
+                bC[jj] = (AF_F16S_ZPAD && !ok[jj]) ? zb[jj] : lb[jj] + cur;
                 bL[jj] = edgeL[jj] ? zb[jj] : bC[jj];
                 bR[jj] = edgeR[jj] ? zb[jj] : bC[jj];
             }
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     if ((XPOS || j + 1 < SPP) && t + 1 < nslabs) {
 #pragma unroll
                         for (int jj = 0; jj < NT; ++jj) {
-                            const uint32_t c_ = lb[jj] + nx1, l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_;
+                            const uint32_t c_ = (AF_F16S_ZPAD && !ok[jj]) ? zb[jj] : lb[jj] + nx1, l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_;
                             fr[b ^ 1][jj][0] = rd(smem, nproj, 0, 0, c_, l_, r_);
                             fr[b ^ 1][jj][1] = rd(smem, nproj, 0, 1, c_, l_, r_);
                         }

@@ -24,11 +24,12 @@ def child():
     from alphafive_amd.network import ResNet
     from oracle import net_fp64
     from test_gpu_net import _positions
-    B, N = int(os.environ.get("B", 4096)), int(os.environ.get("N", 60))
-    net = ResNet(11, device="cuda")
-    net.load_npz(os.path.join(REPO, "tests", "golden", "alphaFive-6960.weights.npz"))
-    hn = net_hip.HipNet(net.variables, 11, B, "cuda")
-    x = _positions(11, B, seed=1)
+    B, N, S = int(os.environ.get("B", 4096)), int(os.environ.get("N", 60)), int(os.environ.get("S", 11))
+    net = ResNet(S, device="cuda", seed=2)
+    if S == 11:
+        net.load_npz(os.path.join(REPO, "tests", "golden", "alphaFive-6960.weights.npz"))
+    hn = net_hip.HipNet(net.variables, S, B, "cuda")
+    x = _positions(S, B, seed=1)
     xb = torch.from_numpy(x).cuda()
     for _ in range(10):
         hn(xb)
