@@ -48,6 +48,9 @@ def lib():
         if not os.path.exists(_LIBPATH):
             raise EngineError(f"{_LIBPATH} not found: build the HIP engine first "
                               f"(python -m alphafive_amd.build). There is no CPU fallback.")
+        # torch first: its wheel bundles its own HIP runtime; a process in which /opt/rocm's copy was pulled in earlier (by this
+        # library's DT_NEEDED) ends up with two runtimes, and the second one finds no device
+        import torch  # noqa: F401
         L = C.CDLL(_LIBPATH)
         vp = C.c_void_p
         i32p, f32p, u64p, u8p = (C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint64),

@@ -21,6 +21,9 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIBPATH):
             raise ImportError(f"{_LIBPATH} not built (python -m alphafive_amd.build)")
+        # torch first: its wheel bundles its own HIP runtime; a process in which /opt/rocm's copy was pulled in earlier (by this
+        # library's DT_NEEDED) ends up with two runtimes, and the second one finds no device
+        import torch  # noqa: F401
         L = C.CDLL(_LIBPATH)
         vp = C.c_void_p
         L.af_net_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]

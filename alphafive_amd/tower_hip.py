@@ -20,6 +20,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIBPATH):
             raise ImportError(f"{_LIBPATH} not built (python -m alphafive_amd.build)")
+        import torch  # noqa: F401  (torch first: see engine.py:lib)
         L = C.CDLL(_LIBPATH)
         vp, fp = C.c_void_p, C.POINTER(C.c_float)
         L.af_tower_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
