@@ -38,11 +38,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (err_ != hipSuccess) return AF_TOWER_ERR_HIP;     \
     } while (0)
 
+// Build-time variants (same experiments as af_conv_f16s.hip, r3; profiles/r3_18_tower_ab.txt): nt hint on the LDS-DMA loads: 5.29 -> 5.17 ms per
+// 8192-position tower pass; lanes past the board read zeros: within noise (5.16-5.17 with both)
+#ifndef AF_TOWER_NT_LOAD
+#define AF_TOWER_NT_LOAD 1
+#endif
+#ifndef AF_TOWER_ZPAD
+#define AF_TOWER_ZPAD 1
+#endif
+
 // LDS-DMA: 16 bytes per lane from global memory into LDS at (wave-uniform lds_dst) + lane*16; counted on vmcnt.
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     unsigned keep;
+#if AF_TOWER_NT_LOAD
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
         uint32_t bC[4], bL[4], bR[4];                                   // read bases for the centre / left / right tap columns
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bC[j] = gcur + lb[j];
+            bC[j] = (AF_TOWER_ZPAD && !ok[j]) ? zb[j] : gcur + lb[j];
             bL[j] = edgeL[j] ? zb[j] : bC[j];
             bR[j] = edgeR[j] ? zb[j] : bC[j];
         }
