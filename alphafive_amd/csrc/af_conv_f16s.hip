@@ -146,13 +146,22 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // LDS-DMA: 16 bytes per lane from global memory into LDS at (wave-uniform lds_dst) + lane*16; counted on vmcnt.
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     unsigned keep;
-#if AF_F16S_NT_LOAD
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    // cache policy of the slab loads (AF_F16S_NT_LOAD: 0 default, 1 nt; 2.. = A/B codes for the scope bits)
+#if AF_F16S_NT_LOAD == 0
+#define AF_F16S_LOAD_POLICY ""
+#elif AF_F16S_NT_LOAD == 1
+#define AF_F16S_LOAD_POLICY " nt"
+#elif AF_F16S_NT_LOAD == 2
+#define AF_F16S_LOAD_POLICY " sc1"
+#elif AF_F16S_NT_LOAD == 3
+#define AF_F16S_LOAD_POLICY " sc1 nt"
+#elif AF_F16S_NT_LOAD == 4
+#define AF_F16S_LOAD_POLICY " sc0 sc1 nt"
 #else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#define AF_F16S_LOAD_POLICY " sc0 nt"
 #endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" AF_F16S_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
