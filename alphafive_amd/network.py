@@ -83,6 +83,8 @@ class ResNet(object):
         self.variables = {}
         self._t = {}
         self._hip_eval = None
+        import threading
+        self._eval_lock = threading.Lock()       # eval() may be called from NetworkAPI's worker thread and the caller's (one set of buffers)
         self.set_variables(random_variables(board_size, seed))
 
     # ---- weights ----
@@ -158,8 +160,9 @@ class ResNet(object):
     def eval(self, inputs):
         """network.py:90-97: numpy float32[B,3,S,S] -> (prob[B,S*S], value[B]) numpy."""
         x = torch.from_numpy(np.ascontiguousarray(inputs, np.float32)).to(self.device)
-        p, v = self.eval_device(x)
-        return p.cpu().numpy(), v.cpu().numpy()
+        with self._eval_lock:                     # (the device evaluator returns views of its own output buffers)
+            p, v = self.eval_device(x)
+            return p.cpu().numpy(), v.cpu().numpy()
 
     # ---- backend selection for the batched engine
     def select_backend(self, name="hip"):
