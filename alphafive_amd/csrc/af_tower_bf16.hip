@@ -459,20 +459,34 @@ __global__ __launch_bounds__(256) void af_tower_stem_kernel(StemArgs A) {
         lb[j] = (uint32_t)nc;                                            // entry index of (cin 0, yy = y, x)
         ob[j] = (uint32_t)(nc + kS) * 16u;
     }
+    // r3 (as in af_stem_mfma_f16s): the planes go through a zero-bordered bf16 image in LDS (rows -2..12, columns -2..13) filled from
+    // registers loaded one position ahead; the im2row entries are built from it instead of five scattered global loads each
+    __shared__ __bf16 img[3 * 15 * 16];
+    for (int i = threadIdx.x; i < 3 * 15 * 16; i += 256) img[i] = (__bf16)0.0f;
+    const int t0 = threadIdx.x, t1 = threadIdx.x + 256;
+    const bool h1 = t1 < 3 * kNPIX;
+    auto img_at = [](int i) -> int { const int c = i / kNPIX, p = i - c * kNPIX, y = p / kS, x = p - y * kS; return (c * 15 + y + 2) * 16 + x + 2; };
+    const int a0 = img_at(t0), a1 = img_at(h1 ? t1 : 0);
+    float nx0 = 0.0f, nx1 = 0.0f;
+    if ((int)blockIdx.x < A.batch) {
+        const float* pl = A.planes + (size_t)blockIdx.x * 3 * kNPIX;
+        nx0 = pl[t0];
+        if (h1) nx1 = pl[t1];
+    }
     for (int pos = blockIdx.x; pos < A.batch; pos += gridDim.x) {
-        const float* pl = A.planes + (size_t)pos * 3 * kNPIX;
         __syncthreads();                                                 // the previous position's reads are done
+        img[a0] = (__bf16)nx0;
+        if (h1) img[a1] = (__bf16)nx1;
+        if (pos + (int)gridDim.x < A.batch) {
+            const float* pl = A.planes + (size_t)(pos + gridDim.x) * 3 * kNPIX;
+            nx0 = pl[t0];
+            if (h1) nx1 = pl[t1];
+        }
+        __syncthreads();
         for (int en = threadIdx.x; en < 3 * 15 * kS; en += 256) {
             const int cin = en / (15 * kS), rem = en - cin * 15 * kS, yy = rem / kS, x = rem - yy * kS;
-            const int y = yy - 2;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (y >= 0 && y < kS) {
-#pragma unroll
-                for (int e = 0; e < 5; ++e) {
-                    const int xx = x - 2 + e;
-                    if (xx >= 0 && xx < kS) v[e] = (__bf16)pl[cin * kNPIX + y * kS + xx];
-                }
-            }
+            const __bf16* src = img + (cin * 15 + yy) * 16 + x;
+            const bf16x8 v = {src[0], src[1], src[2], src[3], src[4], (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
             __builtin_memcpy(&ent[en], &v, 16);
         }
         __syncthreads();
