@@ -274,6 +274,21 @@ def extra_config_legs(timeout_s=240):
         full[name] = {"cmd": " ".join(["python", "bench.py"] + cmd[2:]), "metric": j["metric"], "value": j["value"], "dtype": j["dtype"],
                       "config": j["config"], "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "ms_per_launch")},
                       "time_split": j["time_split"]}
+    # BASELINE configs[0] through the drop-in API: one eval-mode game of the self_play.py:79-106 loop, Player(pv_fn=net.eval) on the
+    # device / HIP-graph path (alphafive_amd/self_play.py) — next to cpu_baseline.config1_eval_mode_value (C port, 1 core)
+    try:
+        r = subprocess.run([sys.executable, "-m", "alphafive_amd.self_play", "--weights-npz",
+                            os.path.join(REPO, "tests", "golden", "alphaFive-6960.weights.npz")], cwd=REPO, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=120)
+        last = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("game finished")]
+        if r.returncode == 0 and last:
+            tok = last[-1].split()                  # "game finished: N plies in T s = X moves/s"
+            flat["config1_player_moves_per_s"] = float(tok[-2])
+            flat["config1_player_plies"] = int(tok[2])
+        else:
+            flat["config1_player_error"] = "rc %d: %s" % (r.returncode, r.stderr.decode()[-200:])
+    except subprocess.TimeoutExpired:
+        flat["config1_player_error"] = "timed out"
     flat["extra_configs"] = full
     return flat
 
