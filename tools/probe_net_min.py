@@ -12,6 +12,9 @@ if os.environ.get("BRANCH") is not None:
     from alphafive_amd import net_hip as _nh
     _nh.tune(4, int(os.environ["BRANCH"]))          # value branch on the side stream (1) or serialised on the main stream (0)
 pv = net.select_backend("hip")
+if os.environ.get("ABLBITS"):
+    from alphafive_amd import net_hip as _nh2
+    _nh2.tune(7, int(os.environ["ABLBITS"]))        # af_conv_f16s ablation bits (1 = no LDS-DMA after the first slabs, 2 = no stores)
 if os.environ.get("MODE"):
     from alphafive_amd import net_hip
     net_hip.tune(0, int(os.environ["MODE"]))
