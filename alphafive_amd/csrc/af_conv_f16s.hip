@@ -1122,7 +1122,9 @@ template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XA
 int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     constexpr int NT = 4 / PS;
     constexpr size_t lds = Lds<G>::kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 * (PJ == 1 ? 2 : 1) : 0);
+#ifndef AF_F16S_NO_LDS_ASSERT                    // (A/B builds with a deeper ring only fit the 11x11 geometry)
     static_assert(lds <= 160 * 1024, "LDS budget");
+#endif
     static bool attr = false;
     if (!attr) {
         FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>),
