@@ -732,9 +732,14 @@ __global__ __launch_bounds__(256) void af_stem_f16s(const float* __restrict__ pl
 // fragment (pixel n, group (cin, ky)) is the 8-wide input window starting at column x-2 of row y+ky-2, pre-expanded into
 // LDS once per position as 3 x 15 x 11 entries of 8 fp16 ("im2row"): one aligned ds_read_b128.  The planes are 0/1 —
 // exact in fp16 — so only the weights are split: two MFMAs per k-step.  One wave = one pixel tile x the 32 couts.
+template <class G>
 __global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict__ planes, const uint4* __restrict__ w /*[8][hi|lo][64]*/,
                                                          const float* __restrict__ bias, float inv_scale, char* __restrict__ out, int batch) {
-    __shared__ __attribute__((aligned(16))) uint4 ent[3 * 15 * kS + 1];     // entry (cin, yy, x) = window x-2..x+5 of row yy-2
+    constexpr int S = G::S, NPIX = G::NPIX, SR = S + 4, IW = S + 5;          // image: rows -2..S+1, IW columns (-2 .. S+2)
+    constexpr int NPL = 3 * NPIX, NLD = (NPL + 255) / 256;                    // plane elements per position / per thread
+    constexpr int NTL = (NPIX + 31) / 32, NRND = (NTL + 3) / 4;               // pixel tiles per position / tile rounds per wave
+    constexpr uint32_t kRowH = Lay<G>::kRowH, kHalfH = Lay<G>::kHalfH, kSlabH = Lay<G>::kSlabH;
+    __shared__ __attribute__((aligned(16))) uint4 ent[3 * SR * S + 1];       // entry (cin, yy, x) = window x-2..x+5 of row yy-2
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     h8 W[16];
@@ -746,68 +751,75 @@ __global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict
     float bs[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bs[r] = bias[16 * kg + r];
-    const int n = 32 * wv + nn;
-    const bool ok = n < kNPIX;
-    const int nc = ok ? n : 0;
-    // r3: the planes of a position go through a zero-bordered fp16 image in LDS (rows -2..12, columns -2..13), filled from
+    // r3: the planes of a position go through a zero-bordered fp16 image in LDS (rows -2..S+1, columns -2..S+2), filled from
     // registers that were loaded one position ahead, and the im2row entries are built from that image — the build used to read
-    // the planes from global memory five scattered words per entry inside the loop (44 -> ~25 us per 4096 positions; same values)
-    __shared__ _Float16 img[3 * 15 * 16];
-    for (int i = threadIdx.x; i < 3 * 15 * 16; i += 256) img[i] = (_Float16)0.0f;
-    const int t0 = threadIdx.x, t1 = threadIdx.x + 256;                         // plane elements of this thread (363 per position)
-    const bool h1 = t1 < 3 * kNPIX;
-    auto img_at = [](int i) -> int { const int c = i / kNPIX, p = i - c * kNPIX, y = p / kS, x = p - y * kS; return (c * 15 + y + 2) * 16 + x + 2; };
-    const int a0 = img_at(t0), a1 = img_at(h1 ? t1 : 0);
-    float nx0 = 0.0f, nx1 = 0.0f;
-    if ((int)blockIdx.x < batch) {
-        const float* pl = planes + (size_t)blockIdx.x * 3 * kNPIX;
-        nx0 = pl[t0];
-        if (h1) nx1 = pl[t1];
+    // the planes from global memory five scattered words per entry inside the loop (11x11: 44 -> 22 us per 4096 positions; same
+    // values).  15x15 (r3): the same kernel, two rounds of four pixel tiles per wave (the VALU stem took 125 us).
+    __shared__ _Float16 img[3 * SR * IW];
+    for (int i = threadIdx.x; i < 3 * SR * IW; i += 256) img[i] = (_Float16)0.0f;
+    auto img_at = [](int i) -> int { const int c = i / NPIX, p = i - c * NPIX, y = p / S, x = p - y * S; return (c * SR + y + 2) * IW + x + 2; };
+    int at[NLD];
+    float nx[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int i = (int)threadIdx.x + 256 * q;
+        at[q] = img_at(i < NPL ? i : 0);
+        nx[q] = 0.0f;
+        if (i < NPL && (int)blockIdx.x < batch) nx[q] = planes[(size_t)blockIdx.x * NPL + i];
     }
     for (int pos = blockIdx.x; pos < batch; pos += gridDim.x) {
         __syncthreads();                                                     // the previous position's reads are done
-        img[a0] = (_Float16)nx0;
-        if (h1) img[a1] = (_Float16)nx1;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)
+            if ((int)threadIdx.x + 256 * q < NPL) img[at[q]] = (_Float16)nx[q];
         if (pos + (int)gridDim.x < batch) {                                  // next position's planes: in flight under this one
-            const float* pl = planes + (size_t)(pos + gridDim.x) * 3 * kNPIX;
-            nx0 = pl[t0];
-            if (h1) nx1 = pl[t1];
+            const float* pl = planes + (size_t)(pos + gridDim.x) * NPL;
+#pragma unroll
+            for (int q = 0; q < NLD; ++q)
+                if ((int)threadIdx.x + 256 * q < NPL) nx[q] = pl[threadIdx.x + 256 * q];
         }
         __syncthreads();
-        for (int en = threadIdx.x; en < 3 * 15 * kS; en += 256) {
-            const int cin = en / (15 * kS), rem = en - cin * 15 * kS, yy = rem / kS, x = rem - yy * kS;
-            const _Float16* src = img + (cin * 15 + yy) * 16 + x;            // padded row yy = board row yy - 2, columns x-2 .. x+2
+        for (int en = threadIdx.x; en < 3 * SR * S; en += 256) {
+            const int cin = en / (SR * S), rem = en - cin * SR * S, yy = rem / S, x = rem - yy * S;
+            const _Float16* src = img + (cin * SR + yy) * IW + x;            // padded row yy = board row yy - 2, columns x-2 .. x+2
             const h8 v = {src[0], src[1], src[2], src[3], src[4], 0, 0, 0};
             __builtin_memcpy(&ent[en], &v, 16);
         }
         __syncthreads();
-        f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int rd_ = 0; rd_ < NRND; ++rd_) {
+            const int n = 32 * (wv + 4 * rd_) + nn;
+            const bool ok = n < NPIX;
+            const int nc = ok ? n : 0;
+            if (32 * (wv + 4 * rd_) >= NPIX) continue;                       // (wave-uniform: this round has no tile for this wave)
+            f32x16 acc;
 #pragma unroll
-        for (int s_ = 0; s_ < 8; ++s_) {
-            // group g = 2 s_ + kg -> (cin, ky); g = 15 is the zero pad of K (its weights are zero: any entry will do)
-            const int ga = 2 * s_, gb = 2 * s_ + 1 < 15 ? 2 * s_ + 1 : 0;
-            const uint32_t offa = (uint32_t)((ga / 5) * 15 + ga % 5) * kS, offb = (uint32_t)((gb / 5) * 15 + gb % 5) * kS;
-            h8 b;
-            __builtin_memcpy(&b, &ent[(uint32_t)nc + (kg ? offb : offa)], 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * s_], b, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * s_ + 1], b, acc, 0, 0, 0);
-        }
-        char* o = out + (size_t)pos * kSlabB + (uint32_t)(2 * kg) * kRowB + (uint32_t)(nc + kS) * 16u;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            h8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = elu1(acc[8 * hf + e] * inv_scale + bs[8 * hf + e]);
-                const _Float16 h = (_Float16)f;
-                hi[e] = h;
-                lo[e] = (_Float16)(f - (float)h);
+            for (int s_ = 0; s_ < 8; ++s_) {
+                // group g = 2 s_ + kg -> (cin, ky); g = 15 is the zero pad of K (its weights are zero: any entry will do)
+                const int ga = 2 * s_, gb = 2 * s_ + 1 < 15 ? 2 * s_ + 1 : 0;
+                const uint32_t offa = (uint32_t)((ga / 5) * SR + ga % 5) * S, offb = (uint32_t)((gb / 5) * SR + gb % 5) * S;
+                h8 b;
+                __builtin_memcpy(&b, &ent[(uint32_t)nc + (kg ? offb : offa)], 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * s_], b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[2 * s_ + 1], b, acc, 0, 0, 0);
             }
-            if (ok) {
-                *reinterpret_cast<h8*>(o + hf * kRowB) = hi;
-                *reinterpret_cast<h8*>(o + hf * kRowB + kHalfB) = lo;
+            char* o = out + (size_t)pos * kSlabH + (uint32_t)(2 * kg) * kRowH + (uint32_t)(nc + G::POFF) * 16u;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                h8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = elu1(acc[8 * hf + e] * inv_scale + bs[8 * hf + e]);
+                    const _Float16 h = (_Float16)f;
+                    hi[e] = h;
+                    lo[e] = (_Float16)(f - (float)h);
+                }
+                if (ok) {
+                    *reinterpret_cast<h8*>(o + hf * kRowH) = hi;
+                    *reinterpret_cast<h8*>(o + hf * kRowH + kHalfH) = lo;
+                }
             }
         }
     }
@@ -1177,7 +1189,7 @@ int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const
     auto get = [&](const std::string& k) -> const std::vector<float>& { return V.at(k); };
     rc = dev_upload(n->allocs, &n->stem_w, get("bone/conv1/kernel").data(), 75 * 32 * 4);
     if (!rc) rc = dev_upload(n->allocs, &n->stem_b, get("bone/conv1/bias").data(), 32 * 4);
-    if (!rc && s11) {       // [k-step s][hi|lo][lane][8]: MFMA row m -> cout perm(m); k = 8*(lane>>5) + e of group g = 2s + (lane>>5) = cin*5 + ky, tap kx = e
+    if (!rc) {              // [k-step s][hi|lo][lane][8]: MFMA row m -> cout perm(m); k = 8*(lane>>5) + e of group g = 2s + (lane>>5) = cin*5 + ky, tap kx = e
         const std::vector<float>& ks = get("bone/conv1/kernel");         // HWIO [5][5][3][32]
         const float sc = pick_scale(ks, nullptr);
         std::vector<_Float16> pk((size_t)8 * 2 * 64 * 8, (_Float16)0.0f);
@@ -1330,13 +1342,16 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
 
 int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes, int batch) {
     if (!n || batch < 1 || batch > n->max_batch) return -1;
-    if (n->S == 15)
-        hipLaunchKernelGGL(af_stem_f16s<Geo<15>>, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
-    else if (n->abl & 16)    // A/B: the VALU stem
-        hipLaunchKernelGGL(af_stem_f16s<Geo<11>>, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
-    else
-        hipLaunchKernelGGL(af_stem_mfma_f16s, dim3(std::min(batch, 1024)), dim3(256), 0, st, planes, n->stem_wm, n->stem_b, n->stem_inv_scale,
+    if (n->abl & 16) {       // A/B: the VALU stem
+        if (n->S == 15) hipLaunchKernelGGL(af_stem_f16s<Geo<15>>, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
+        else hipLaunchKernelGGL(af_stem_f16s<Geo<11>>, dim3(std::min(batch, 2048)), dim3(256), 0, st, planes, n->stem_w, n->stem_b, n->f0, batch);
+    } else if (n->S == 15) {
+        hipLaunchKernelGGL(af_stem_mfma_f16s<Geo<15>>, dim3(std::min(batch, 1024)), dim3(256), 0, st, planes, n->stem_wm, n->stem_b, n->stem_inv_scale,
                            n->f0, batch);
+    } else {
+        hipLaunchKernelGGL(af_stem_mfma_f16s<Geo<11>>, dim3(std::min(batch, 1024)), dim3(256), 0, st, planes, n->stem_wm, n->stem_b, n->stem_inv_scale,
+                           n->f0, batch);
+    }
     int rc = launch_layer(n, st, 0, n->f0, nullptr, n->g[0], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 1, n->g[0], n->f0, n->o[0], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 2, n->o[0], nullptr, n->g[1], nullptr, batch, 0, 0);
