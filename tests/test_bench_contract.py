@@ -1,0 +1,50 @@
+"""The one JSON line `python bench.py` prints, checked on the line the GPU box produced last (committed under profiles/): the
+keys the driver's contract names, the roofline / cpu_baseline objects, and the arithmetic that ties them together."""
+import glob
+import json
+import os
+
+from conftest import REPO
+
+
+def _last_line():
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r3_*_bench_driver_command.json")))
+    assert files, "no committed bench line of this round"
+    with open(files[-1]) as f:
+        lines = [ln for ln in f if ln.startswith("{")]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_carries_the_contract():
+    d = _last_line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("self-play moves/sec (11x11, 500 sims/move)") and d["unit"] == "moves/s"
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    assert "4096 concurrent 11x11 games" in d["config"]["workload"]
+    # value = plies committed / wall time; a step commits one ply per game
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["games_per_gpu"]) < 0.02 * d["config"]["games_per_gpu"]
+    assert d["config"]["episodes_finished_in_timed_region"] > 0            # steady state, not the opening phase
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or 0.9 < r["traffic"] / r["hbm_algorithmic_bytes_per_launch"] < 1.5   # counters vs algorithmic bytes
+    # the dominant kernel cannot take longer than a step allows
+    ticks = d["config"]["ticks_timed_rank0"] / d["steps"]
+    assert ticks * (r["ms_per_launch"] + d["tree_roofline"]["ms_per_launch"]) < 1.03 * d["ms_per_step"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["unit"] == "moves/s" and c["value"] > 0
+
+
+def test_extra_config_legs_are_flat_scalars():
+    d = _last_line()
+    for name in ("config4", "config5"):
+        assert isinstance(d[name + "_moves_per_s"], float) and d[name + "_moves_per_s"] > 0
+        assert d[name + "_episodes_finished"] > 0 and d[name + "_net_ms"] > 0 and 0 < d[name + "_mfma_frac"] < 1
+    assert "15x15" in d["extra_configs"]["config4"]["metric"] and d["extra_configs"]["config5"]["dtype"] == "bf16"
