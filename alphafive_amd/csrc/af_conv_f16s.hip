@@ -75,9 +75,8 @@ constexpr uint32_t kLds0 = 256u;                // slack so that unit -1 of a sl
 #define AF_F16S_DIST 3
 #endif
 constexpr int kDist = AF_F16S_DIST;             // prefetch distance in slabs: slab t multiplies while t+1 .. t+kDist land
-constexpr int kRing = kDist + 2;                // LDS slots (see the fragment prefetch in the kernel)
-template <class G> struct Lds {
-    static constexpr uint32_t kZoff = kLds0 + kRing * Lay<G>::kSlotL;    // all-zero region (edge lanes)
+template <class G, int DIST = kDist> struct Lds {                        // DIST + 2 LDS slots (see the fragment prefetch in the kernel)
+    static constexpr uint32_t kZoff = kLds0 + (DIST + 2) * Lay<G>::kSlotL;    // all-zero region (edge lanes)
     static constexpr uint32_t kBiasOff = kZoff + Lay<G>::kSlotL;         // 128 floats
     static constexpr uint32_t kScrOff = kBiasOff + 512u;                 // k-split exchange
 };
@@ -203,12 +202,16 @@ struct F16sArgs {
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
 };
 
-template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD>
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_conv_f16s(F16sArgs A) {
+// DIST: prefetch distance of this instantiation (default kDist); WPE: waves per SIMD = workgroups per CU.  WPE = 2 (r3) is for the
+// narrow layers whose whole register need fits 256: with DIST = 1 the ring is 3 slots (74 KB per workgroup), two workgroups share
+// a CU and one's epilogue / barriers / waits run under the other's MFMAs.
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST = kDist, int WPE = 1>
+__global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void af_conv_f16s(F16sArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using L = Lay<G>;
     constexpr uint32_t kRowH = L::kRowH, kHalfH = L::kHalfH, kSlabH = L::kSlabH, kRowL = L::kRowL, kHalfL = L::kHalfL, kSlotL = L::kSlotL;
-    constexpr uint32_t kZoff = Lds<G>::kZoff, kBiasOff = Lds<G>::kBiasOff, kScrOff = Lds<G>::kScrOff;
+    constexpr uint32_t kZoff = Lds<G, DIST>::kZoff, kBiasOff = Lds<G, DIST>::kBiasOff, kScrOff = Lds<G, DIST>::kScrOff;
+    constexpr int kDist = DIST, kRing = DIST + 2;                             // (shadow the file-level default)
     constexpr int NPC = G::NPC, HV = G::HALVES;
     constexpr int NT = 4 / PS;                    // pixel tiles per wave
     constexpr int C16 = 2 / KS;                   // 16-channel k-steps per slab and wave
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     static_assert(CT * KS * PS == 4 && NT >= KS, "4 waves");
     static_assert(PJ == 0 || NSP == 0, "a producer / consumer of the separate projection has no projection slabs");
     constexpr int NPW = PJ == 1 ? NSM * C16 : 0;  // projection items (centre tap of every k-step)
-    static_assert(NPC * (kDist - 1) < 64, "vmcnt is a 6-bit field");
+    static_assert(NPC * (DIST > 1 ? DIST - 1 : 1) < 64, "vmcnt is a 6-bit field");
+    static_assert(DIST >= 2 || (NSP == 0 && ITM - 1 >= NPC), "distance 1: a slab's pieces must all be issued before its predecessor's last item");
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ct = wv % CT, ks = (wv / CT) % KS, ps = wv / (CT * KS);
@@ -1130,23 +1134,24 @@ std::vector<_Float16> pack_frags(int nfrag, F&& val) {          // [fragment][hi
     return out;
 }
 
-template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ = 0, int HD = 0>
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ = 0, int HD = 0, int DIST = kDist, int WPE = 1>
 int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     constexpr int NT = 4 / PS;
-    constexpr size_t lds = Lds<G>::kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 * (PJ == 1 ? 2 : 1) : 0);
+    constexpr size_t lds = Lds<G, DIST>::kScrOff + (KS == 2 ? (size_t)CT * PS * NT * 4096 * (PJ == 1 ? 2 : 1) : 0);
+    static_assert(WPE * lds <= 160 * 1024, "LDS budget of the workgroups sharing a CU");
 #ifndef AF_F16S_NO_LDS_ASSERT                    // (A/B builds with a deeper ring only fit the 11x11 geometry)
     static_assert(lds <= 160 * 1024, "LDS budget");
 #endif
     static bool attr = false;
     if (!attr) {
-        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>),
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     // one workgroup per CU, a multiple of HALVES of them (a workgroup keeps one half of the board for the whole launch)
-    int gx = std::max(1, std::min(a.batch * G::HALVES, ncu / gy));
+    int gx = std::max(1, std::min(a.batch * G::HALVES, WPE * ncu / gy));
     gx = std::max(G::HALVES, gx / G::HALVES * G::HALVES);
-    hipLaunchKernelGGL((af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD>), dim3(gx, gy), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE>), dim3(gx, gy), dim3(256), lds, st, a);
     return 0;
 }
 
@@ -1314,18 +1319,27 @@ void f16s_set_ablation(f16s_net* n, int bits) { if (n) n->abl = bits; }
 template <class G>
 static int launch_layer_g(f16s_net* n, hipStream_t st, int li, const F16sArgs& a, int head) {
     switch (li) {
-        case 0: return launch_cfg<G, 1, 0, 2, 1, 2, false, true>(st, a, 1, n->ncu);
+        // the three 32-channel-input layers (one slab per position): two workgroups per CU, prefetch distance 1 (abl bit 5 = the
+        // one-workgroup instantiation, for A/B)
+        // (11x11 only: two 3-slot rings of 20-KB slots + zero regions exceed 160 KB on 15x15)
+        case 0:
+            if constexpr (G::S == 11) { if (!(n->abl & 32)) return launch_cfg<G, 1, 0, 2, 1, 2, false, false, 0, 0, 1, 2>(st, a, 1, n->ncu); }   // (no XACC: 256 registers)
+            return launch_cfg<G, 1, 0, 2, 1, 2, false, true>(st, a, 1, n->ncu);
         case 1: return launch_cfg<G, 2, 1, 2, 1, 2, false, true>(st, a, 1, n->ncu);
         case 2: return launch_cfg<G, 2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
         case 3: return launch_cfg<G, 4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
         case 4: return launch_cfg<G, 4, 0, 1, 2, 2, false, false, 1>(st, a, 1, n->ncu);   // (no XACC: weights + projection weights + 3 accumulator sets would spill)
-        case 5: return head == 0 ? launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 1>(st, a, 1, n->ncu)
-                                 : launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);   // (one pixel tile per wave, whole K: no k-split exchange)
+        case 5:                                                                           // (one pixel tile per wave, whole K: no k-split exchange)
+            if constexpr (G::S == 11) { if (head == 0 && !(n->abl & 32)) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 1, 1, 2>(st, a, 1, n->ncu); }
+            if (head == 0) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 1>(st, a, 1, n->ncu);
+            return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
         case 6: return launch_cfg<G, 4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
         case 7: return launch_cfg<G, 2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
         case 8: return launch_cfg<G, 2, 0, 1, 1, 4, false, true, 1>(st, a, 1, n->ncu);
-        default: return head == 1 ? launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 2>(st, a, 1, n->ncu)
-                                  : launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
+        default:
+            if constexpr (G::S == 11) { if (head == 1 && !(n->abl & 32)) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 2, 1, 2>(st, a, 1, n->ncu); }
+            if (head == 1) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 2>(st, a, 1, n->ncu);
+            return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
     }
 }
 
