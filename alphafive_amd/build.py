@@ -33,9 +33,11 @@ def _stale(out, srcs):
 
 
 def build_all(force=False, verbose=True):
+    """Build every stale library; the (independent) hipcc invocations run side by side."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    built = []
+    built, jobs = [], []
     for name, (srcs, extra) in TARGETS.items():
         out = os.path.join(LIBDIR, name)
         srcs = [os.path.join(PKG, s) for s in srcs]
@@ -43,8 +45,13 @@ def build_all(force=False, verbose=True):
             cmd = [hipcc] + HIPCC_FLAGS + extra + ["-o", out] + srcs
             if verbose:
                 print("[alphafive_amd.build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
         built.append(out)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            for rc, cmd in zip(ex.map(subprocess.call, jobs), jobs):
+                if rc != 0:
+                    raise subprocess.CalledProcessError(rc, cmd)
     return built
 
 
