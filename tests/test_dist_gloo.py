@@ -1,6 +1,9 @@
-"""N>1 path on CPU: world_size-2 gloo run of the episode gather, weight broadcast and move counter."""
+"""N>1 path on CPU: world_size-2 and -8 gloo runs of the episode gather, weight broadcast and move counter (8 = the rank count of
+BASELINE configs[2]: one process per GPU of a node)."""
 import os
 import socket
+
+import pytest
 
 import numpy as np
 import torch
@@ -48,39 +51,40 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_world2_gather_broadcast_allreduce():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gather_broadcast_allreduce(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in ps]
     res = {}
-    for _ in range(2):
-        r = q.get(timeout=120)
+    for _ in range(world):
+        r = q.get(timeout=240)
         res[r[0]] = r
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
     expect = []
-    for rank in range(2):
+    for rank in range(world):
         for i in range(2 + rank):
             e = _episode(rank, i, 5 + 3 * i + rank)
             expect.append((e["game"] + rank * 1000, e["seq"], e["T"], e["final_value"], float(e["policies"].sum()),
                            int(e["visits"].sum()), int(e["keys"].sum() % 1000003)))
     assert sorted(res[0][1]) == sorted(expect)          # rank 0 holds everyone's episodes, bit-exact
-    assert res[1][1] == []
-    assert res[0][2] == res[1][2] == sum(t[2] for t in expect)
-    assert res[0][3] == res[1][3]                       # identical weights after the broadcast
+    assert all(res[r][1] == [] for r in range(1, world))
+    assert all(res[r][2] == sum(t[2] for t in expect) for r in range(world))
+    assert all(res[r][3] == res[0][3] for r in range(world))   # identical weights after the broadcast
     want = []
     for step in range(5):                               # pipelined gather: everything arrives at rank 0, in (step, rank) order
-        for rank in range(2):
+        for rank in range(world):
             for i in range((step + rank) % 4):
                 e = _episode(rank, 10 * step + i, 4 + i + step)
                 want.append((e["game"] + rank * 1000, e["T"], int(e["visits"].sum())))
-    assert res[0][4] == want and res[1][4] == []
+    assert res[0][4] == want and all(res[r][4] == [] for r in range(1, world))
     assert res[0][5][:2] == [0, 0]                      # nothing can arrive before two steps have passed (sizes, then payload)
-    assert res[0][6] > 0 and res[1][6] == 0             # only rank 0 receives payload bytes
+    assert res[0][6] > 0 and all(res[r][6] == 0 for r in range(1, world))   # only rank 0 receives payload bytes
 
 
 def test_pack_unpack_roundtrip_empty_and_ragged():
