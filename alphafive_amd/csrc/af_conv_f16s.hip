@@ -106,6 +106,12 @@ constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB
 #ifndef AF_F16S_NT_STORE
 #define AF_F16S_NT_STORE 0
 #endif
+#ifndef AF_F16S_APIN
+#define AF_F16S_APIN 1          // weights beyond AF_F16S_VW registers are pinned into accumulator registers (MFMA A operands)
+#endif
+#ifndef AF_F16S_VW
+#define AF_F16S_VW 128          // architectural VGPRs given to weight fragments
+#endif
 #ifndef AF_F16S_NT_LOAD
 #define AF_F16S_NT_LOAD 1
 #endif
@@ -335,8 +341,19 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
         lb[jj] = kLds0 + (uint32_t)((KS == 2 ? 2 * ks : 0) + kg) * kRowL + (uint32_t)((nc + G::POFF - G::S - 1 - (int)G::wbase(hv)) * 16);
         zb[jj] = kZoff + (lb[jj] & 255u);
     }
+    // Pin the weight loads before the loop (see af_tower_bf16.hip).  Where the weights do not fit the 256 architectural VGPRs
+    // next to the fragment buffers, the surplus is pinned into accumulator registers ("+a"), from which the MFMA takes its A operand
+    // directly: with "+v" for all of them hipcc parked the surplus there anyway and copied every fragment back with four
+    // v_accvgpr_read before use (0.7-2 VALU instructions per MFMA in the item loop of the wide layers; r3_38).
+    constexpr int kAccRegs = 16 * NT * (1 + (XACC ? 1 : 0) + (PJ == 1 ? 1 : 0));
+    constexpr int kWRegs = 4 * (2 * NIT + (PJ == 1 ? 2 * NPW : 0) + (HD > 0 ? 4 : 0));
+    constexpr int kNAmax = (256 - kAccRegs - 16) / 4, kNAwant = (kWRegs - AF_F16S_VW + 3) / 4;
+    constexpr int NA = (AF_F16S_APIN && WPE == 1 && kNAwant > 0) ? (kNAwant < kNAmax ? kNAwant : kNAmax) : 0;
 #pragma unroll
-    for (int f = 0; f < 2 * NIT; ++f) asm volatile("" : "+v"(W[f]));      // pin the weight loads before the loop (see af_tower_bf16.hip)
+    for (int f = 0; f < 2 * NIT; ++f) {
+        if (f < 2 * NIT - NA) asm volatile("" : "+v"(W[f]));
+        else asm volatile("" : "+a"(W[f]));
+    }
     if (PJ == 1) {
 #pragma unroll
         for (int f = 0; f < 2 * NPW; ++f) asm volatile("" : "+v"(PW[f]));

@@ -46,6 +46,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef AF_TOWER_ZPAD
 #define AF_TOWER_ZPAD 1
 #endif
+#ifndef AF_TOWER_VSLACK
+#define AF_TOWER_VSLACK 88       // architectural VGPRs left to everything that is not a weight fragment or the B-fragment ring
+#endif
+#ifndef AF_TOWER_ABL_NOLDS
+#define AF_TOWER_ABL_NOLDS 0     // profiling build: af_tower_conv without its B-fragment reads (results wrong by design)
+#endif
 
 // LDS-DMA: 16 bytes per lane from global memory into LDS at (wave-uniform lds_dst) + lane*16; counted on vmcnt.
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
@@ -134,8 +140,16 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
     // Pin the weight / bias loads' completion HERE: hipcc otherwise sinks its counted vmcnt waits to the first use of
     // each fragment inside the position loop, where they would also wait for the (to hipcc invisible) LDS-DMA of the
     // next position that is issued at the top of every iteration.
+    constexpr int kNVfit = (256 - 4 * DEPTH - AF_TOWER_VSLACK) / 4, kNVmin = NS - (256 - 64) / 4;   // fragments kept in VGPRs
+    constexpr int NV = kNVfit > kNVmin ? kNVfit : kNVmin;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(W[s]));
+    for (int s = 0; s < NS; ++s) {
+        // 288 [320] weight registers do not fit the 256 architectural VGPRs: the upper half is pinned into accumulator registers,
+        // which the MFMA reads as its A operand directly ("+v" for all of them made hipcc park them there anyway and copy each
+        // fragment back with four v_accvgpr_read before use: one VALU instruction per MFMA in the hot loop)
+        if (s < NV) asm volatile("" : "+v"(W[s]));
+        else asm volatile("" : "+a"(W[s]));
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bias_r[r]));
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // first planes landed, zero region written
@@ -178,7 +192,9 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
         for (int i = 0; i < NM; ++i) {
             const int ws = i < NPJ ? 72 + (i >> 2) : (i - NPJ) >> 2;
             acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[ws], ring[i % DEPTH], acc[i & 3], 0, 0, 0);
-            if (i + DEPTH < NM && !(A.abl & 8)) ring[i % DEPTH] = rd(i + DEPTH);   // abl bit 3 (profiling): no LDS reads
+            // (no run-time condition here: a profiling bit tested at this point cost a branch and four register moves per MFMA,
+            // r2 -> r3_37; the "no LDS reads" ablation is the build-time macro AF_TOWER_ABL_NOLDS)
+            if (i + DEPTH < NM && !AF_TOWER_ABL_NOLDS) ring[i % DEPTH] = rd(i + DEPTH);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
             // the next position's planes are requested one 4 KB piece every 16 MFMAs (an LDS-DMA costs ~5 issue slots:
