@@ -86,6 +86,31 @@ __device__ __forceinline__ u64 rfl64(u64 x) {
     return ((u64)rfl32((uint32_t)(x >> 32)) << 32) | (u64)rfl32((uint32_t)x);
 }
 __device__ __forceinline__ float rflf(float x) { return __int_as_float(rfli(__float_as_int(x))); }
+// Wave-wide maximum, the same value in every lane, on the DPP cross-lane paths of the VALU (quad permutes, row mirrors, row
+// broadcasts) + one v_readlane: ~10 instructions where six __shfl_xor rounds cost six ds_bpermute round trips through the LDS
+// crossbar (~100 cycles each) on the critical path of every select.  max is exact and order-free, so the result is the same bits.
+template <int CTRL, int ROWS = 0xF>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xF, false); }
+__device__ __forceinline__ int wave_max_i32(int v) {
+    int o;
+    o = dpp_i<0xB1>(v); v = o > v ? o : v;            // quad_perm [1,0,3,2]
+    o = dpp_i<0x4E>(v); v = o > v ? o : v;            // quad_perm [2,3,0,1]
+    o = dpp_i<0x141>(v); v = o > v ? o : v;           // row_half_mirror
+    o = dpp_i<0x140>(v); v = o > v ? o : v;           // row_mirror: every lane of a 16-lane row holds the row's maximum
+    o = dpp_i<0x142, 0xA>(v); v = o > v ? o : v;      // row_bcast:15 into rows 1 and 3
+    o = dpp_i<0x143, 0xC>(v); v = o > v ? o : v;      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    float o;
+    o = __int_as_float(dpp_i<0xB1>(__float_as_int(v))); v = o > v ? o : v;
+    o = __int_as_float(dpp_i<0x4E>(__float_as_int(v))); v = o > v ? o : v;
+    o = __int_as_float(dpp_i<0x141>(__float_as_int(v))); v = o > v ? o : v;
+    o = __int_as_float(dpp_i<0x140>(__float_as_int(v))); v = o > v ? o : v;
+    o = __int_as_float(dpp_i<0x142, 0xA>(__float_as_int(v))); v = o > v ? o : v;
+    o = __int_as_float(dpp_i<0x143, 0xC>(__float_as_int(v))); v = o > v ? o : v;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 
 template <int KW>
 __device__ __forceinline__ void bb_shr(const u64* a, int d, u64* o) {   // 0 < d < 64
@@ -241,7 +266,7 @@ __device__ int tree_lookup(const EngineParams& P, int g, const u64* mine, const 
         const u64 mm = __ballot(match);
         if (mm) {
             const int src = __builtin_ctzll(mm);
-            return (int)__shfl((int)v, src) - 1;
+            return __builtin_amdgcn_readlane((int)v, src) - 1;          // (src is wave-uniform: it comes from a ballot)
         }
         if (first_empty < 64) {
             *slot_out = (h + round * 64 + first_empty) & P.hash_mask;
@@ -524,8 +549,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 nv[k] = lg ? (en[(size_t)ridx * CP + lane + 64 * k] & 0x7fffffff) : -1;
                 most = nv[k] > most ? nv[k] : most;
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(most, off); most = o > most ? o : most; }
+            most = wave_max_i32(most);
             u64 best[KW];
 #pragma unroll
             for (int k = 0; k < KW; ++k) best[k] = __ballot(nv[k] == most && nv[k] >= 0);
@@ -853,8 +877,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 if (m > 0) cell = bb_select<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1));
             }
             if (cell < 0) {                                                 // :277-279 argmax with uniform tie-break
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+                mx = wave_max_f32(mx);
                 u64 cand[KW];
 #pragma unroll
                 for (int k = 0; k < KW; ++k) cand[k] = __ballot(((legal[k] >> lane) & 1ull) && sc[k] == mx);
@@ -864,7 +887,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             cell = rfli(cell);
             hint = 0;
 #pragma unroll
-            for (int k = 0; k < KW; ++k) { const int t_ = __shfl(cc[k], cell & 63); if ((cell >> 6) == k) hint = t_; }
+            for (int k = 0; k < KW; ++k) { const int t_ = __builtin_amdgcn_readlane(cc[k], cell & 63); if ((cell >> 6) == k) hint = t_; }   // (cell is wave-uniform)
             hint = rfli(hint);
             pidx = idx; pcl = cell;
             if (hint) {
