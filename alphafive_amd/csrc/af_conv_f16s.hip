@@ -106,6 +106,11 @@ constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB
 #ifndef AF_F16S_NT_STORE
 #define AF_F16S_NT_STORE 0
 #endif
+#ifndef AF_F16S_M0CLOB
+#define AF_F16S_M0CLOB 0          // A/B (r3_43): m0 declared clobbered by the LDS-DMA asm instead of saved / restored around it: -0.2 %, but hipcc
+#endif                            // warns that a clobber of the reserved m0 "may not be preserved": not adopted
+// (r3_43, rejected: requesting past the end of the slab stream — the last position again — so that no branch surrounds the LDS-DMA
+//  instructions: +1 %, the surplus loads cost more than the branches)
 #ifndef AF_F16S_APIN
 #define AF_F16S_APIN 1          // weights beyond AF_F16S_VW registers are pinned into accumulator registers (MFMA A operands)
 #endif
@@ -165,11 +170,33 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 #else
 #define AF_F16S_LOAD_POLICY " sc0 nt"
 #endif
+#if AF_F16S_M0CLOB
+    (void)keep;                 // A/B: m0 declared clobbered instead of saved and restored around the instruction
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" AF_F16S_LOAD_POLICY
+                 : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" AF_F16S_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+// ELU as max(x, min(exp(x), 1) - 1): the same bits as x > 0 ? x : exp(x) - 1 (exp(x) - 1 > x for x < 0; the clamped exponential is
+// exactly 1 for x >= 0), one v_max_f32 instead of compare + select, and the clamp rides on v_exp_f32 (r3_44)
+__device__ __forceinline__ float elu1(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    return fmaxf(x, fminf(fmaxf(e, 0.0f), 1.0f) - 1.0f);
+}
+// ... and two at a time on 2-vectors, which keeps the bias add in front and the "- 1" as v_pk_add_f32 (hipcc's SLP vectoriser pairs them
+// in the compare / select form but not in the max form): 3 + v_exp_f32 instead of 4 + v_exp_f32 issue slots per element
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 elu2(f32x2 x) {
+    const f32x2 t = x * 1.44269504088896341f;
+    f32x2 e;
+    e.x = fminf(fmaxf(__builtin_amdgcn_exp2f(t.x), 0.0f), 1.0f);
+    e.y = fminf(fmaxf(__builtin_amdgcn_exp2f(t.y), 0.0f), 1.0f);
+    const f32x2 em1 = e - 1.0f;
+    return f32x2{fmaxf(x.x, em1.x), fmaxf(x.y, em1.y)};
+}
 
 #ifdef AF_F16S_TIMING
 // profiling build only (tools/probe_f16s_timing.py): cycles per phase, [layer][workgroup (x + 256 y)][wave][phase]
@@ -601,10 +628,11 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
             if (!mine) continue;
             float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pre = acc[jj][r] * A.inv_scale + bs[r];
-                if (PJ == 2) pre += padd[jj % NFIN][r / 4][r % 4];       // (a wave's own tiles are jj / NFIN == ks)
-                v[r] = elu1(pre);
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 pre = f32x2{acc[jj][r], acc[jj][r + 1]} * A.inv_scale + f32x2{bs[r], bs[r + 1]};
+                if (PJ == 2) pre += f32x2{padd[jj % NFIN][r / 4][r % 4], padd[jj % NFIN][r / 4][r % 4 + 1]};   // (a wave's own tiles are jj / NFIN == ks)
+                const f32x2 y = elu2(pre);
+                v[r] = y.x; v[r + 1] = y.y;
             }
             if (HD > 0) {
                 // a lane holds channels 16 kg + r of its pixel: r = 0..7 and r = 8..15 are the B fragments of two k-steps whose k

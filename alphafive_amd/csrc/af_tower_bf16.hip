@@ -65,7 +65,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 #endif
 }
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+// ELU as max(x, min(exp(x), 1) - 1): the same bits as x > 0 ? x : exp(x) - 1 (exp(x) - 1 > x for x < 0; the clamped exponential is
+// exactly 1 for x >= 0), one v_max_f32 instead of compare + select, and the clamp rides on v_exp_f32 (r3_44)
+__device__ __forceinline__ float elu1(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    return fmaxf(x, fminf(fmaxf(e, 0.0f), 1.0f) - 1.0f);
+}
+// ... and two at a time on 2-vectors, which keeps the bias add in front and the "- 1" as v_pk_add_f32 (hipcc's SLP vectoriser pairs them
+// in the compare / select form but not in the max form): 3 + v_exp_f32 instead of 4 + v_exp_f32 issue slots per element
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 elu2(f32x2 x) {
+    const f32x2 t = x * 1.44269504088896341f;
+    f32x2 e;
+    e.x = fminf(fmaxf(__builtin_amdgcn_exp2f(t.x), 0.0f), 1.0f);
+    e.y = fminf(fmaxf(__builtin_amdgcn_exp2f(t.y), 0.0f), 1.0f);
+    const f32x2 em1 = e - 1.0f;
+    return f32x2{fmaxf(x.x, em1.x), fmaxf(x.y, em1.y)};
+}
 
 struct TowerArgs {
     const char* in;      // C8 bf16 [batch][16][PIX][8]: input of the 3x3 convolution
@@ -219,7 +235,10 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
             for (int hf = 0; hf < 2; ++hf) {
                 bf16x8 v;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (__bf16)elu1(acc[j][8 * hf + e] + bias_r[8 * hf + e]);
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 y = elu2(f32x2{acc[j][8 * hf + e], acc[j][8 * hf + e + 1]} + f32x2{bias_r[8 * hf + e], bias_r[8 * hf + e + 1]});
+                    v[e] = (__bf16)y.x; v[e + 1] = (__bf16)y.y;
+                }
                 if (ok[j] && !(A.abl & 2)) *reinterpret_cast<bf16x8*>(o + (uint32_t)((4 * wv + 2 * kg + hf) * kPIX) * 16u + ob[j]) = v;
             }
     }
