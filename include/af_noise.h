@@ -46,8 +46,10 @@ AF_HD af_u32x4 af_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
     const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = af_mulhi32(M0, c0), lo0 = M0 * c0;
-        uint32_t hi1 = af_mulhi32(M1, c2), lo1 = M1 * c2;
+        /* (one 64-bit product per multiplier: on the GPU a single v_mad_u64_u32 instead of v_mul_hi_u32 + v_mul_lo_u32) */
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0, p1 = (uint64_t)M1 * (uint64_t)c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0;
         uint32_t n1 = lo1;
         uint32_t n2 = hi0 ^ c3 ^ k1;
