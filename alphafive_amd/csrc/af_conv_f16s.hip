@@ -958,7 +958,10 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
     extern __shared__ __attribute__((aligned(16))) char psm[];
     constexpr int NPIX = G::NPIX, HXP = Hx<G>::HXP, NLT = Hx<G>::NLT, MT = NLT / 4, RD = 16 / MT, NCH = HXP / 32, LW = 32 * NLT;
     static_assert(NLT % 4 == 0 && LW * 32 * 4 <= (int)kPfLds, "logit tiles");
-    const int t = threadIdx.x & 255, kh = threadIdx.x >> 8, lane = t & 63, mt = t >> 6, n = lane & 31, kg = lane >> 5;
+    // kh and mt are wave-uniform: as scalars (readfirstlane) the step bounds below are scalar branches; as functions of threadIdx they
+    // were exec-masked regions whose ring refills hipcc waited for on the spot (vmcnt(0) after every refill: r3_47)
+    const int t = threadIdx.x & 255, lane = t & 63, n = lane & 31, kg = lane >> 5;
+    const int kh = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), mt = __builtin_amdgcn_readfirstlane(t >> 6);
     const int b0 = (int)blockIdx.x * 32;
     char* const sm = psm + (uint32_t)kh * 2u * kPfBuf;
     // K half kh = chunks NCH kh .. NCH kh + NCH - 1 of 16 pixels (the last ones are partly / wholly past S*S).  Staging of a
@@ -1003,7 +1006,8 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int step = 16 * c + q;
-            if (step < nstep) {
+            {   // steps past the board (K half 1: pixels S*S .. HXP-1) run too: their B fragments are the zero pixel slots of the head
+                // buffer and the A fragment is the last valid step's again, so they add exact zeros — and the body has no condition
                 const h8 bh = *reinterpret_cast<const h8*>(bb + (uint32_t)(2 * q) * kPfRow);
                 const h8 bl = *reinterpret_cast<const h8*>(bb + (uint32_t)(2 * (16 + q)) * kPfRow);
 #pragma unroll
@@ -1011,9 +1015,10 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
                     h8 ah, al;
                     __builtin_memcpy(&ah, &ring[q % RD][m][0], 16);
                     __builtin_memcpy(&al, &ring[q % RD][m][1], 16);
-                    if (step + RD < nstep) {
-                        ring[q % RD][m][0] = ap[((size_t)(step + RD) * NLT + 4 * m) * 128];
-                        ring[q % RD][m][1] = ap[((size_t)(step + RD) * NLT + 4 * m) * 128 + 64];
+                    {   // refill unconditionally (past the end: the last step again, never used): no branch, no phi around the loads
+                        const int pf = step + RD < nstep ? step + RD : nstep - 1;
+                        ring[q % RD][m][0] = ap[((size_t)pf * NLT + 4 * m) * 128];
+                        ring[q % RD][m][1] = ap[((size_t)pf * NLT + 4 * m) * 128 + 64];
                     }
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m], 0, 0, 0);
