@@ -260,6 +260,11 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ct = wv % CT, ks = (wv / CT) % KS, ps = wv / (CT * KS);
+    // k-split: register slot jj of a wave holds pixel tile (jj + rot) mod NT, so that the tiles a wave finishes are ALWAYS its slots
+    // 0 .. NFIN-1 and the ones it hands to its partner its slots NFIN .. NT-1: exchange, combine and epilogue are unconditional
+    // straight-line code (with "tile jj / NFIN == ks" they were branches on ks, and every accumulator made a round trip through
+    // v_accvgpr_write / v_accvgpr_read at the merge points)
+    const int rot = KS == 2 ? ks * (NT / KS) : 0;
     const int ctg = (int)blockIdx.y * CT + ct, nso = (int)gridDim.y * CT;
     const uint32_t lds = (uint32_t)(uintptr_t)smem;
 
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     bool ok[NT], edgeL[NT], edgeR[NT];
 #pragma unroll
     for (int jj = 0; jj < NT; ++jj) {
-        const int n = 128 * hv + 32 * (ps * NT + jj) + nn;
+        const int n = 128 * hv + 32 * (ps * NT + ((jj + rot) & (NT - 1))) + nn;
         ok[jj] = n < G::NPIX;
         const int nc = ok[jj] ? n : 128 * hv;                                // (an invalid lane works on the half's first pixel)
         pix[jj] = nc;
@@ -564,10 +569,10 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
 #define AF_EXCHANGE(ACC, SCR)                                                                                              \
     {                                                                                                                      \
         _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                                \
-            if ((jj / NFIN) != ks) {                                                                                       \
+            if (jj >= NFIN) {                                                                                              \
                 _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
                     f32x4 v = {ACC[jj][4 * q], ACC[jj][4 * q + 1], ACC[jj][4 * q + 2], ACC[jj][4 * q + 3]};                \
-                    *reinterpret_cast<f32x4*>((SCR) + (uint32_t)(jj * 4 + q) * 1024u + lane * 16u) = v;                    \
+                    *reinterpret_cast<f32x4*>((SCR) + (uint32_t)(((jj + rot) & (NT - 1)) * 4 + q) * 1024u + lane * 16u) = v; \
                 }                                                                                                          \
             }                                                                                                              \
         }                                                                                                                  \
@@ -575,9 +580,9 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
 #define AF_COMBINE(ACC, SCR)                                                                                               \
     {                                                                                                                      \
         _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                                \
-            if ((jj / NFIN) == ks) {                                                                                       \
+            if (jj < NFIN) {                                                                                               \
                 _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
-                    const f32x4 v = *reinterpret_cast<const f32x4*>((SCR) + (uint32_t)(jj * 4 + q) * 1024u + lane * 16u);  \
+                    const f32x4 v = *reinterpret_cast<const f32x4*>((SCR) + (uint32_t)(((jj + rot) & (NT - 1)) * 4 + q) * 1024u + lane * 16u); \
                     ACC[jj][4 * q] += v[0]; ACC[jj][4 * q + 1] += v[1]; ACC[jj][4 * q + 2] += v[2]; ACC[jj][4 * q + 3] += v[3]; \
                 }                                                                                                          \
             }                                                                                                              \
@@ -601,8 +606,8 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
         if (PJ == 1) {                                                       // the projection, fp32, in accumulator layout
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
-                if (KS == 2 && (jj / NFIN) != ks) continue;
-                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + ps * NT + jj) * 4) * 64 + lane;
+                if (KS == 2 && jj >= NFIN) continue;
+                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + ps * NT + ((jj + rot) & (NT - 1))) * 4) * 64 + lane;
                 if (!(A.abl & 2)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -624,13 +629,13 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
         }
 #pragma unroll
         for (int jj = 0; jj < NT; ++jj) {
-            const bool mine = KS == 1 || (jj / NFIN) == ks;
+            const bool mine = KS == 1 || jj < NFIN;
             if (!mine) continue;
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 f32x2 pre = f32x2{acc[jj][r], acc[jj][r + 1]} * A.inv_scale + f32x2{bs[r], bs[r + 1]};
-                if (PJ == 2) pre += f32x2{padd[jj % NFIN][r / 4][r % 4], padd[jj % NFIN][r / 4][r % 4 + 1]};   // (a wave's own tiles are jj / NFIN == ks)
+                if (PJ == 2) pre += f32x2{padd[jj % NFIN][r / 4][r % 4], padd[jj % NFIN][r / 4][r % 4 + 1]};   // (a wave's own tiles are its slots 0 .. NFIN-1)
                 const f32x2 y = elu2(pre);
                 v[r] = y.x; v[r + 1] = y.y;
             }
