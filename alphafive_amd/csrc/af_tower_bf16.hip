@@ -65,8 +65,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 #endif
 }
 
-// ELU as max(x, min(exp(x), 1) - 1): the same bits as x > 0 ? x : exp(x) - 1 (exp(x) - 1 > x for x < 0; the clamped exponential is
-// exactly 1 for x >= 0), one v_max_f32 instead of compare + select, and the clamp rides on v_exp_f32 (r3_44)
+// ELU as max(x, min(exp(x), 1) - 1): x > 0 ? x : exp(x) - 1 with one v_max_f32 instead of compare + select and the clamp riding on
+// v_exp_f32 (r3_44).  exp(x) - 1 > x for x < 0 and the clamped exponential is exactly 1 for x >= 0; only for -3e-4 < x < 0 can the
+// rounding of v_exp_f32 put exp(x) - 1 below x, and the max then returns x, within 5e-8 of the true value (see af_conv_f16s.hip)
 __device__ __forceinline__ float elu1(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
     return fmaxf(x, fminf(fmaxf(e, 0.0f), 1.0f) - 1.0f);
