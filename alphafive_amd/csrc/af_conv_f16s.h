@@ -12,7 +12,8 @@
 struct f16s_net;
 
 // variables under their checkpoint names in TF layout (as af_net_set_variable received them); board sizes 11 (one pseudo-position
-// per board, heads fused) and 15 (two half-board pseudo-positions; the heads run on af_net.hip's kernels from fp32 planes)
+// per board) and 15 (two half-board pseudo-positions per board); on both the heads are fused (the 1x1 head convolutions ride the last conv
+// of each branch, the dense layers run on af_value_fc_f16s / af_policy_fc_f16s<Geo<S>>)
 int f16s_supported(int board_size);
 int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const std::map<std::string, std::vector<float>>& vars);
 void f16s_destroy(f16s_net* n);

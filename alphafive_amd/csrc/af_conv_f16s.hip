@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <string>
@@ -1207,16 +1208,22 @@ int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
 #ifndef AF_F16S_NO_LDS_ASSERT                    // (A/B builds with a deeper ring only fit the 11x11 geometry)
     static_assert(lds <= 160 * 1024, "LDS budget");
 #endif
-    static bool attr = false;
-    if (!attr) {
+    // the attribute belongs to the (function, device) pair: one bit per device for this instantiation (a process may drive
+    // several GPUs, one handle each; handles are created on their own device and launched with it current)
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    FS_HIP_OK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
         FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        attr_devs.fetch_or(bit, std::memory_order_relaxed);
     }
     // one workgroup per CU, a multiple of HALVES of them (a workgroup keeps one half of the board for the whole launch)
     int gx = std::max(1, std::min(a.batch * G::HALVES, WPE * ncu / gy));
     gx = std::max(G::HALVES, gx / G::HALVES * G::HALVES);
     hipLaunchKernelGGL((af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE>), dim3(gx, gy), dim3(256), lds, st, a);
+    FS_HIP_OK(hipGetLastError());                   // a rejected launch (LDS attribute, grid) must not pass silently
     return 0;
 }
 
@@ -1380,7 +1387,7 @@ void f16s_destroy(f16s_net* n) {
 void f16s_set_ablation(f16s_net* n, int bits) { if (n) n->abl = bits; }
 
 // the ten layers on one board geometry.  <NSM, NSP, CT, KS, PS, OUT32, XACC[, PJ, HD]>: XACC wherever weights + 2 x accumulators +
-// fragments fit 512 registers; the fused head variants (HD) exist for 11x11 only
+// fragments fit 512 registers; the fused head variants (HD = 1 value, 2 policy) are launched for both geometries
 template <class G>
 static int launch_layer_g(f16s_net* n, hipStream_t st, int li, const F16sArgs& a, int head) {
     switch (li) {

@@ -141,6 +141,10 @@ class Engine:
         self.mode = mode & ~MODE_VALUE_F64
         self.device = device
         self._status = np.zeros(num_games, np.int32)
+        # host-mutable fields of the by-value EngineParams a launch is issued with (training flag, simulation budget, per-launch
+        # select budget): a captured HIP graph has them baked in, so whoever replays one keys it on params_key()
+        self._params = {"training": int(bool(training)), "sims": int(self.cfg.simulation_per_step),
+                        "upper": int(self.cfg.upper_simulation_per_step), "tick_budget": None}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -159,12 +163,19 @@ class Engine:
         _check(rc, "engine status")
         return self._status
 
+    def params_key(self):
+        """Everything set_training / set_simulations / set_tick_budget can change: part of the key of any captured graph."""
+        p = self._params
+        return (p["training"], p["sims"], p["upper"], p["tick_budget"])
+
     def set_training(self, training):
         _check(lib().af_engine_set_training(self._h, int(training)), "af_engine_set_training")
+        self._params["training"] = int(bool(training))
 
     def set_simulations(self, sims, upper):
         """Budget of the moves that start from now on (the reference reads config.simulation_per_step at every get_action)."""
         _check(lib().af_engine_set_simulations(self._h, int(sims), int(upper)), "af_engine_set_simulations")
+        self._params["sims"], self._params["upper"] = int(sims), int(upper)
 
     def set_root(self, game, key, last_cell=-1, random_a=False, reset_tree=False):
         key = np.ascontiguousarray(key, np.uint64)
@@ -215,6 +226,7 @@ class Engine:
 
     def set_tick_budget(self, selects_per_launch):
         _check(lib().af_engine_set_tick_budget(self._h, int(selects_per_launch)), "af_engine_set_tick_budget")
+        self._params["tick_budget"] = int(selects_per_launch)
 
     def progress(self, stream=None):
         out = np.zeros(2, np.uint64)

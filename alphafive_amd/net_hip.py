@@ -141,8 +141,9 @@ def roofline_info(board_size=11):
         # the same kernels on two half-board pseudo-positions per board (8 pixel tiles of 32 for 225 pixels): MFMA work per
         # position = 256 / 121 of the 11x11 figure; HBM slabs are 32 KB (reads: 2 x 20 KB windows, writes 2 x 15.5 / 12.4 KB)
         return {"backend": "hip (af_conv_f16s.hip on 15x15: two half-board pseudo-positions per board, fp16 split operands, fp32 "
-                           "accumulation; VALU stem; heads fused like 11x11)",
-                "kernel": "af_net_forward = af_stem_f16s + 10x af_conv_f16s<Geo<15>> + af_value_fc_f16s + af_policy_fc_f16s (whole "
+                           "accumulation; MFMA stem and fused heads as on 11x11)",
+                "kernel": "af_net_forward = af_stem_mfma_f16s<Geo<15>> + 10x af_conv_f16s<Geo<15>> (the last conv of each branch also "
+                          "applies the head's 1x1 convolution) + af_value_fc_f16s<Geo<15>> + af_policy_fc_f16s<Geo<15>> (whole "
                           "forward timed)",
                 "peak_tflops": 2500.0, "issued_flop_per_position": 2 * 3 * _SPLIT_MAC_PER_PIXEL * 256,
                 "algorithmic_bytes_per_position": (30 * 2 * 20480 + 19 * 30720 + 2 * 2 * 2 * 16384 + 2 * (4 + 16) * 225 * 2 * 2 + 3 * 225 * 4 + 226 * 4)}

@@ -82,8 +82,8 @@ class ResNet(object):
         self.api = None
         self.variables = {}
         self._t = {}
-        self._hip_eval = None
         import threading
+        self._hip_eval = threading.local()       # eval_device(): one hand-written-kernel evaluator per calling thread
         self._eval_lock = threading.Lock()       # eval() may be called from NetworkAPI's worker thread and the caller's (one set of buffers)
         self.set_variables(random_variables(board_size, seed))
 
@@ -150,11 +150,15 @@ class ResNet(object):
 
     def eval_device(self, x):
         """x float32[B,3,S,S] on self.device -> (prob float32[B,S*S], value float32[B]) on device.  cuda: the hand-written
-        kernels (the returned tensors are views of the evaluator's output buffers, valid until the next call)."""
+        kernels (the returned tensors are views of the calling thread's evaluator output buffers, valid until that thread's
+        next call)."""
         if self.device.type == "cuda":
-            if self._hip_eval is None:
-                self._hip_eval = self.select_backend("hip")      # raises without libaf_net.so: no vendor-op fallback
-            return self._hip_eval(x.contiguous())
+            # one evaluator (kernel handle + output buffers) PER THREAD: NetworkAPI's worker thread calling eval() and a
+            # SelfPlayEngine(pv_device=net.eval_device) on the caller's thread never share output buffers
+            ev = getattr(self._hip_eval, "fn", None)
+            if ev is None:
+                ev = self._hip_eval.fn = self.select_backend("hip")      # raises without libaf_net.so: no vendor-op fallback
+            return ev(x.contiguous())
         return self.eval_torch(x)
 
     def eval(self, inputs):

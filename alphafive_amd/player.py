@@ -217,7 +217,9 @@ class Player(object):
                 self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), stream)
                 self._evaluate_leaf()
             return
-        key = (bool(self.training), self._weights_version())
+        # ... and on every host-mutable launch parameter (EngineParams travel by value: training flag, the simulation budget the
+        # reference re-reads from the live config at every get_action (player.py:140-143), the per-launch select budget)
+        key = (self._engine.params_key(), self._weights_version())
         if self._graph is None or self._graph[0] != key:
             self._graph = None
             cur = torch.cuda.current_stream(self._dev)

@@ -119,4 +119,8 @@ def train_loop(config, engine, net, stack, trainer, steps, log=print):
                     (step, metrics["cross_entropy"], metrics["value_loss"], metrics["entropy"]))
                 if step % 60 == 0:
                     trainer.save(config.ckpt_path, step)
+        if on_device:
+            # a packed append that found its buffer not to hold what the header said appends nothing and raises a device flag,
+            # while the host bookkeeping has already advanced: surface it here, once per hand-off, before the ring is sampled again
+            stack.check()
     return step

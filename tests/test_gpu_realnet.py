@@ -101,7 +101,7 @@ def test_player_device_graph_path_matches_oracle_at_the_metric_settings(training
     assert pl.backend == "hip"
     orc = oracle.OraclePlayer(cfg, training=training, rng_mode=oracle.RNG_PHILOX, seed=11, game_id=2, pv_fn=eval_np)
     _drive(pl, orc, training, 8)
-    assert pl._graph is not None and pl._graph[1] is not None and pl._graph[0][0] == training      # the HIP-graph path ran
+    assert pl._graph is not None and pl._graph[1] is not None and pl._graph[0][0][0] == int(training)      # the HIP-graph path ran
     _compare_tree(pl._engine.tree_dump(0), orc, 11)
     assert len(pl.tree) == orc.tree_size()
     pl.close()
@@ -155,6 +155,36 @@ def test_player_graph_path_follows_a_weight_update():
     assert pl._graph[0] != g0[0] and pl._graph[1] is not g0[1]  # dropped and captured again
     net.load_npz(W)
     _drive(pl, orc, True, 2, state=state, last=last)
+    _compare_tree(pl._engine.tree_dump(0), orc, 11)
+    pl.close()
+
+
+def test_player_graph_path_follows_the_live_simulation_budget():
+    """player.py:140-143 reads config.simulation_per_step / upper_simulation_per_step at every get_action.  EngineParams travel by
+    value, so a captured graph has the budget baked in: the graph is keyed on Engine.params_key() and captured again when the
+    caller changes the budget between two moves (the stale graph kept replaying the old budget)."""
+    from alphafive_amd.network import ResNet
+    from alphafive_amd.player import Player
+    from test_gpu_parity import _compare_tree
+    import torch
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    opv = net.select_backend("hip")
+
+    def eval_np(x):
+        p, v = opv(torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda())
+        return p.cpu().numpy().copy(), v.cpu().numpy().copy()
+    cfg = make_cfg(simulation_per_step=120, upper_simulation_per_step=160)
+    pl = Player(cfg, training=True, pv_fn=net.eval, seed=8, game_id=1)
+    orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=8, game_id=1, pv_fn=eval_np)
+    state, last, keys = None, None, []
+    for sims, upper in ((120, 160), (30, 40), (200, 420), (120, 160)):
+        cfg.simulation_per_step, cfg.upper_simulation_per_step = sims, upper
+        orc.set_simulations(sims, upper)
+        state, last = _drive(pl, orc, True, 2, state=state, last=last)
+        assert pl._graph is not None and pl._graph[0][0][1:3] == (sims, upper)
+        keys.append(pl._graph[0])
+    assert len(set(keys)) == 3
     _compare_tree(pl._engine.tree_dump(0), orc, 11)
     pl.close()
 
