@@ -214,6 +214,8 @@ __device__ __forceinline__ f32x2 elu2(f32x2 x) {
 // phase 0 items (MFMA + reads + DMA issue), 1 vmcnt waits, 2 slab barriers, 3 k-split exchange (7: its barrier alone), 4 epilogue,
 // 5 total, 6 positions; 8 start-up (kernel entry -> weights and first slabs in place)
 __device__ unsigned long long g_f16s_cycles[10][512][4][9];
+// [layer][workgroup][0 = entry, 1 = exit]: the device-wide 100 MHz clock (s_memrealtime), for the spread of workgroup finish times
+__device__ unsigned long long g_f16s_wall[10][512][2];
 #define AF_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define AF_TACC(slot, a, b) tacc[slot] += (b) - (a)
 #else
@@ -287,6 +289,9 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     const int hv = HV == 1 ? 0 : qpos % HV;
     const uint32_t wsrc = G::wbase(hv) * 16u;          // byte offset of the half's window inside a unit row (HBM)
     AF_T(t_entry);
+#ifdef AF_F16S_TIMING
+    const unsigned long long wall_entry = wall_clock64();
+#endif
 
     // slab j of a position: the NSP slabs of the projection input first, then the NSM slabs of the 3x3 input (the other
     // order — long slabs first, so that the epilogue's stores have more time before the next wait on vmcnt — measured
@@ -735,6 +740,7 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
         const int layer = (A.abl >> 8) & 15;
         for (int q = 0; q < 8; ++q) g_f16s_cycles[layer][blockIdx.x + 256 * blockIdx.y][wv][q] = tacc[q];
         g_f16s_cycles[layer][blockIdx.x + 256 * blockIdx.y][wv][8] = t_ready - t_entry;
+        if (wv == 0) { g_f16s_wall[layer][blockIdx.x + 256 * blockIdx.y][0] = wall_entry; g_f16s_wall[layer][blockIdx.x + 256 * blockIdx.y][1] = wall_clock64(); }
     }
 #endif
 }
@@ -1503,6 +1509,11 @@ int f16s_read_activation(f16s_net* n, int which, int batch, float* host) {
 extern "C" int af_f16s_debug_cycles(unsigned long long* host) {
     FS_HIP_OK(hipDeviceSynchronize());
     FS_HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_f16s_cycles), sizeof(unsigned long long) * 10 * 512 * 4 * 9));
+    return 0;
+}
+extern "C" int af_f16s_debug_wall(unsigned long long* host) {
+    FS_HIP_OK(hipDeviceSynchronize());
+    FS_HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_f16s_wall), sizeof(unsigned long long) * 10 * 512 * 2));
     return 0;
 }
 #endif

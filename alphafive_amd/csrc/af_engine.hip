@@ -1483,6 +1483,12 @@ int af_engine_progress(af_engine* e, void* stream, uint64_t* out) {
     return AF_OK;
 }
 
+int af_engine_progress_async(af_engine* e, void* stream, uint64_t* out_pinned) {
+    if (!e || !out_pinned) return AF_ERR_ARG;
+    HIP_OK(hipMemcpyAsync(out_pinned, e->P.progress, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return AF_OK;
+}
+
 int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys, int32_t* sum_n, int32_t* n,
                         float* w, float* p, uint8_t* f32) {
     if (!e || game < 0 || game >= e->P.G) return AF_ERR_ARG;

@@ -14,6 +14,8 @@ collective on the tick path).  The only exchanges are the ones SURVEY §8e lists
 
 Backend: torch.distributed "nccl" (= RCCL over xGMI) on GPUs; "gloo" in the CPU tests.
 """
+import time as _time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -54,12 +56,38 @@ def unpack_episodes(buf, max_eps=None):
     return _unpack_packed(buf, int(buf[0]) if max_eps is None else max_eps)
 
 
-def _localise(b, max_eps, r, games_per_rank):
-    eps = _unpack_packed(b, max_eps)
-    if games_per_rank:
-        for e in eps:
-            e["game"] += r * games_per_rank
-    return eps
+class PackedEpisodes(object):
+    """One rank's finished episodes as rank 0 received them: a numpy int32 VIEW of the packed hand-off layout
+    (af_engine_pack_episodes) in one of EpisodeGather's pinned host buffers.  Reading `n` / `plies` touches the 4-int header
+    only; episodes() unpacks into raw episode dicts (game ids made global) — call it when the records are needed (a trainer's
+    push), from any thread, before the buffer is recycled: the view stays valid through the collect() after the one that
+    returned it (the second one after it overwrites the buffer); copy() detaches it."""
+    __slots__ = ("buf", "max_eps", "rank", "games_per_rank")
+
+    def __init__(self, buf, max_eps, rank, games_per_rank):
+        self.buf, self.max_eps, self.rank, self.games_per_rank = buf, max_eps, rank, games_per_rank
+
+    @property
+    def n(self):
+        return int(self.buf[0])
+
+    @property
+    def plies(self):
+        return int(self.buf[1])
+
+    def lengths(self):
+        """T of every episode (header only)."""
+        return self.buf[4:4 + 4 * self.n].reshape(-1, 4)[:, 2]
+
+    def copy(self):
+        return PackedEpisodes(self.buf.copy(), self.max_eps, self.rank, self.games_per_rank)
+
+    def episodes(self):
+        eps = _unpack_packed(self.buf, self.max_eps)
+        if self.games_per_rank:
+            for e in eps:
+                e["game"] += self.rank * self.games_per_rank
+        return eps
 
 
 def _run_collectives(world):
@@ -70,15 +98,25 @@ def _run_collectives(world):
 class EpisodeGather(object):
     """Pipelined gather of packed episode buffers to rank 0.  Per step, in this order on every rank:
 
-        eps = g.collect()                      # advances the buffers posted earlier; rank 0 gets finished payloads
+        got = g.collect(unpack=False)          # advances the buffers posted earlier; rank 0 gets finished payloads
         buf = sp.post_episodes_device(cap)     # this step's pack kernels (they overwrite the engine's pack buffer)
         g.post(buf)                            # sizes all-gather on the device, read back asynchronously
         ...
-        eps += g.flush()                       # at the end: drains everything (blocking)
+        got += g.flush(unpack=False)           # at the end: drains everything (blocking)
 
-    collect() must come before the next pack: the gather it issues reads the previously posted buffer.
+    collect() must come before the next pack: the gather it issues reads the previously posted buffer (the collective is
+    ordered with the current stream, so the pack that follows cannot overtake it).
+    Rank 0's share of a step is O(world) small calls and no per-episode work: sizes (one event that retired a step ago),
+    one gather into a receive buffer that is allocated once, one strided device-to-pinned copy into a ring of pinned
+    buffers that is allocated once, and — with unpack=False — PackedEpisodes views whose headers carry the counts
+    (bench.py reads n / plies only; a trainer unpacks where it needs the records, see PackedEpisodes).  unpack=True
+    (default, tests and one-off callers) returns raw episode dicts as before.
     max_eps / rec_ints describe the pack layout (af_engine_pack_episodes: used = 4 + 5*max_eps + plies*rec_ints).
-    `device`: where the collectives run — the GPU for "nccl" (= RCCL over xGMI), cpu for "gloo"."""
+    `device`: where the collectives run — the GPU for "nccl" (= RCCL over xGMI), cpu for "gloo".
+    stats: host seconds spent in collect() / post() on this rank, split into time inside torch.distributed calls
+    (enqueue-only under RCCL, blocking under gloo) and everything else (`host_s`, thread CPU time)."""
+
+    RING = 3                                  # pinned payload buffers: delivered views outlive two more collects
 
     def __init__(self, world, rank, device, max_eps, rec_ints, games_per_rank=0):
         self.world, self.rank, self.device = world, rank, torch.device(device)
@@ -86,26 +124,63 @@ class EpisodeGather(object):
         self.collective = world > 1 or _run_collectives(world)
         self._tickets = []
         self.bytes_received = 0           # rank 0: payload bytes that crossed the fabric towards it
+        self._pin = torch.cuda.is_available()
+        self._sizes_host = [torch.zeros(world, dtype=torch.int64, pin_memory=self._pin) for _ in range(self.RING + 1)]
+        self._sizes_dev = [None] * (self.RING + 1)
+        self._turn = 0
+        self._recv = None                 # rank 0: [world, cap] int32 on `device`
+        self._host = [None] * self.RING   # rank 0: pinned [world, cap] int32
+        self._host_turn = 0
+        self.allocations = 0              # buffer (re)allocations so far: constant once the run has seen its widest step
+        self.stats = {"steps": 0, "wall_s": 0.0, "host_s": 0.0, "comm_s": 0.0}
 
-    def _pinned(self, n, dtype):
-        return torch.empty(n, dtype=dtype, pin_memory=torch.cuda.is_available())
+    # ---- buffers: grown geometrically, i.e. allocated once per size class ----
+    def _ensure(self, width):
+        """-> (receive buffer [world, >= width] on `device`, pinned host buffer of this turn).  On a cpu `device` (gloo) the
+        collective receives straight into the host ring: there is no second copy."""
+        k = self._host_turn
+        on_host = self.device.type != "cuda"
+        have = self._host[k].shape[1] if self._host[k] is not None else 0
+        want = max(have, self._recv.shape[1] if self._recv is not None else 0)
+        if want < width:
+            want = int(width * 1.5) + 1024
+        if not on_host and (self._recv is None or self._recv.shape[1] < want):
+            self._recv = torch.empty((self.world, want), dtype=torch.int32, device=self.device)
+            self.allocations += 1
+        if have < want:
+            self._host[k] = torch.empty((self.world, want), dtype=torch.int32, pin_memory=self._pin)
+            self.allocations += 1
+        return (self._host[k] if on_host else self._recv), self._host[k]
+
+    def _comm(self, fn, *a, **kw):
+        t0 = _time.thread_time()
+        out = fn(*a, **kw)
+        self.stats["comm_s"] += _time.thread_time() - t0
+        return out
 
     def post(self, buf):
         """buf: the packed int32 buffer of this step (device tensor).  Issues the sizes exchange; returns at once."""
+        w0, c0 = _time.perf_counter(), _time.thread_time()
+        k = self._turn = (self._turn + 1) % len(self._sizes_host)
         used = (buf[1:2].to(torch.int64) * self.rec_ints + (4 + 5 * self.max_eps))          # stays on the device
         if self.collective:
-            allsz = torch.empty(self.world, dtype=torch.int64, device=self.device)
-            dist.all_gather_into_tensor(allsz, used.to(self.device))
+            if self._sizes_dev[k] is None:
+                self._sizes_dev[k] = torch.empty(self.world, dtype=torch.int64, device=self.device)
+            allsz = self._sizes_dev[k]
+            self._comm(dist.all_gather_into_tensor, allsz, used.to(self.device))
         else:
             allsz = used
+        host = self._sizes_host[k]
         if allsz.device.type == "cuda":
-            host = self._pinned(self.world, torch.int64)
             host.copy_(allsz, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(allsz.device))
         else:
-            host, ev = allsz.clone(), None
+            host.copy_(allsz)
+            ev = None
         self._tickets.append({"stage": 0, "buf": buf, "sizes": host, "ev": ev})
+        self.stats["wall_s"] += _time.perf_counter() - w0
+        self.stats["host_s"] += _time.thread_time() - c0
 
     def _gather(self, t):
         if t["ev"] is not None:
@@ -117,44 +192,44 @@ class EpisodeGather(object):
             payload = payload.to(self.device)
         if payload.numel() < width:               # a caller-built buffer smaller than the widest payload (gather_episodes)
             payload = torch.cat([payload, torch.zeros(width - payload.numel(), dtype=torch.int32, device=self.device)])
-        if self.collective:
-            dst = [torch.empty(width, dtype=torch.int32, device=self.device) for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(payload.contiguous(), dst, dst=0)          # grouped send/recv towards rank 0: no other rank receives
-        else:
-            dst = [payload]
-        t.update(stage=1, buf=None, sizes=sizes)
+        t.update(stage=1, buf=None, sizes=sizes, host=None)
         if self.rank != 0:
+            if self.collective:
+                self._comm(dist.gather, payload.contiguous(), None, dst=0)     # grouped send towards rank 0: no other rank receives
             t["stage"] = 2
-            t["host"] = None
             return
+        recv, host = self._ensure(width)
+        self._host_turn = (self._host_turn + 1) % self.RING
+        if self.collective:
+            self._comm(dist.gather, payload.contiguous(), [recv[r, :width] for r in range(self.world)], dst=0)
+        else:
+            recv[0, :width].copy_(payload)
         self.bytes_received += sum(sizes[1:]) * 4
-        hosts, ev = [], None
-        for r in range(self.world):
-            src = dst[r][:sizes[r]]
-            if src.device.type == "cuda":
-                h = self._pinned(sizes[r], torch.int32)
-                h.copy_(src, non_blocking=True)
-                hosts.append(h)
-            else:
-                hosts.append(src.clone())
-        if self.device.type == "cuda" or t.get("ev") is not None:
+        ev = None
+        if recv.device.type == "cuda":
+            host[:, :width].copy_(recv[:, :width], non_blocking=True)          # ONE strided copy: rows of `width` ints
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-        t["host"], t["ev"] = hosts, ev
+            ev.record(torch.cuda.current_stream(recv.device))
+        t["host"], t["ev"] = host, ev
 
-    def _unpack(self, t):
+    def _deliver(self, t, unpack):
         if t["host"] is None:
             return []
         if t["ev"] is not None:
             t["ev"].synchronize()
-        out = []
-        for r, h in enumerate(t["host"]):
-            out += _localise(h.numpy(), self.max_eps, r, self.games_per_rank)
-        return out
+        h = t["host"].numpy()
+        out = [PackedEpisodes(h[r, :t["sizes"][r]], self.max_eps, r, self.games_per_rank) for r in range(self.world)]
+        if not unpack:
+            return out
+        eps = []
+        for pk in out:
+            eps += pk.episodes()
+        return eps
 
-    def collect(self, drain=False):
-        """Advance every posted buffer by one stage (all of them to the end with drain=True); -> rank 0: the episodes
-        whose payload has arrived, other ranks: []."""
+    def collect(self, drain=False, unpack=True):
+        """Advance every posted buffer by one stage (all of them to the end with drain=True); -> rank 0: what has arrived
+        (raw episode dicts, or one PackedEpisodes per rank and step with unpack=False), other ranks: []."""
+        w0, c0 = _time.perf_counter(), _time.thread_time()
         out, keep = [], []
         for t in self._tickets:
             if t["stage"] == 0:
@@ -162,12 +237,20 @@ class EpisodeGather(object):
                 if not drain:
                     keep.append(t)
                     continue
-            out += self._unpack(t)
+            out += self._deliver(t, unpack)
         self._tickets = keep
+        self.stats["steps"] += 1
+        self.stats["wall_s"] += _time.perf_counter() - w0
+        self.stats["host_s"] += _time.thread_time() - c0
         return out
 
-    def flush(self):
-        return self.collect(drain=True)
+    def flush(self, unpack=True):
+        return self.collect(drain=True, unpack=unpack)
+
+    def handoff_ms_per_step(self):
+        """-> (wall ms, host-work ms outside torch.distributed calls) this rank spent in collect() + post() per step."""
+        n = max(1, self.stats["steps"])
+        return 1e3 * self.stats["wall_s"] / n, 1e3 * (self.stats["host_s"] - self.stats["comm_s"]) / n
 
 
 def gather_packed(buf, max_eps, world, rank, device, games_per_rank=0):

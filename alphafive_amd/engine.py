@@ -81,6 +81,7 @@ def lib():
         L.af_engine_tree_w64.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
         L.af_engine_set_tree_w64.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
         L.af_engine_progress.argtypes = [vp, vp, u64p]
+        L.af_engine_progress_async.argtypes = [vp, vp, vp]
         L.af_engine_tick_histogram.argtypes = [vp, vp, u64p, C.c_int32]
         L.af_engine_set_tick_budget.argtypes = [vp, C.c_int32]
         L.af_engine_tree_dump.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
@@ -233,6 +234,10 @@ class Engine:
         _check(lib().af_engine_progress(self._h, stream, _p(out, C.c_uint64)), "af_engine_progress")
         return int(out[0]), int(out[1])
 
+    def progress_async(self, out_ptr, stream=None):
+        """The 16-byte progress copy without the wait (ABI v4): out_ptr = pinned host memory; stream-ordered, capturable."""
+        _check(lib().af_engine_progress_async(self._h, stream, out_ptr), "af_engine_progress_async")
+
     def tree_dump(self, game):
         cnt = _check(lib().af_engine_tree_dump(self._h, game, 0, None, None, None, None, None, None), "tree_dump")
         keys = np.zeros((cnt, self.KW2), np.uint64)
@@ -350,6 +355,8 @@ class SelfPlayEngine:
             pv_device.bind_outputs(self.policy, self.value)
         self.ticks = 0
         self._boxes = {}
+        self._graph = None
+        self._prog_host, self._prog_events, self._prog_turn, self._prog_replays = None, None, 0, 0
 
     def tick(self):
         """One simulation step for every game: tree kernel -> leaf batch -> net."""
@@ -368,6 +375,49 @@ class SelfPlayEngine:
             self.tick()
             if check_every and (i + 1) % check_every == 0:
                 self.check()
+
+    # ---- the steady-state loop as a HIP graph: n x (tree kernel -> leaf batch -> net) + the progress words, one launch ----
+    def _graph_key(self, n):
+        ver = getattr(self.pv_device, "weights_version", None)
+        return (int(n), self.engine.params_key(), ver() if callable(ver) else None)
+
+    def run_ticks_graph(self, n=16):
+        """n ticks replayed as ONE HIP graph on the current stream (the tick kernel, the forward's 13 launches with the value
+        branch's fork / join, and at the end a 16-byte copy of the engine's progress words into pinned host memory).  Returns at
+        once; progress_lagged() reads the words one replay later, so polling never drains the device.  The graph is keyed on
+        everything a launch has baked in: n, the engine's by-value parameters (training flag, simulation budget, per-launch select
+        budget) and the evaluator's weight version — a change drops it, one eager tick re-packs the weights and the batch is
+        captured again (same protocol as Player._search_batch).  A failing capture raises: there is no silent eager fallback."""
+        torch = self.torch
+        key = self._graph_key(n)
+        if self._graph is None or self._graph[0] != key:
+            self._graph = None
+            if self._prog_host is None:
+                self._prog_host = torch.zeros(2, dtype=torch.int64, pin_memory=True)
+                self._prog_events = [torch.cuda.Event(), torch.cuda.Event()]
+            self.tick()                              # outside the capture: weight reload, lazy allocations, side-stream creation
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    self.tick()
+                st = torch.cuda.current_stream(self.dev).cuda_stream
+                self.engine.progress_async(self._prog_host.data_ptr(), st)
+            self.ticks -= n                          # (capture recorded the launches, it did not run them)
+            self._graph = (self._graph_key(n), g)
+        self._graph[1].replay()
+        self.ticks += n
+        self._prog_turn ^= 1
+        self._prog_events[self._prog_turn].record(torch.cuda.current_stream(self.dev))
+        self._prog_replays += 1
+
+    def progress_lagged(self):
+        """(plies committed, episodes finished) as of the end of the PREVIOUS run_ticks_graph() replay or later: waits for that
+        replay's event only — the newest replay keeps the device busy meanwhile."""
+        if self._prog_replays < 2:
+            return 0, 0
+        self._prog_events[self._prog_turn ^ 1].synchronize()
+        return int(self._prog_host[0]), int(self._prog_host[1])
 
     def check(self):
         stream = self.torch.cuda.current_stream(self.dev).cuda_stream
@@ -409,14 +459,16 @@ class SelfPlayEngine:
         box["posted"] = True
         return box
 
-    def collect_episodes(self, cap=256):
-        """-> raw episode dicts of the last post_episodes(cap) (waits for its event only)."""
+    def collect_episodes(self, cap=256, unpack=True):
+        """-> raw episode dicts of the last post_episodes(cap) (waits for its event only).  unpack=False: the packed int32
+        buffer itself (numpy view of the pinned memory, valid until the next post_episodes(cap); buf[0] = episodes,
+        buf[1] = plies: a caller that only counts reads the header and does no per-episode work), or None."""
         box = self._outbox(cap)
         if not box["posted"]:
-            return []
+            return [] if unpack else None
         box["event"].synchronize()
         box["posted"] = False
-        return unpack_episodes(box["buf"].numpy(), cap)
+        return unpack_episodes(box["buf"].numpy(), cap) if unpack else box["buf"].numpy()
 
     def pop_raw(self, cap=256):
         self.post_episodes(cap)

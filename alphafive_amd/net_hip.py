@@ -119,6 +119,7 @@ def make_eval(resnet):
             state["net"].bind_outputs(policy, value)
 
     pv.bind_outputs = bind_outputs
+    pv.weights_version = lambda: getattr(resnet, "version", None)      # what a captured graph of this evaluator is keyed on
     return pv
 
 

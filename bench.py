@@ -304,7 +304,11 @@ def main():
     ap.add_argument("--upper", type=int, default=642)
     ap.add_argument("--board", type=int, default=11, help="board size (15 with --sims 800 --upper 942 = BASELINE configs[3])")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--poll", type=int, default=8, help="ticks between progress polls")
+    ap.add_argument("--poll", type=int, default=16, help="ticks per progress poll (= ticks per HIP-graph replay with --loop graph)")
+    ap.add_argument("--loop", default="graph", choices=["graph", "eager"],
+                    help="graph (default): the steady-state loop replays --poll x (tick + forward) as ONE HIP graph and reads the "
+                         "progress words one replay late, so the host never drains the device; one eager chunk per step carries the "
+                         "HIP events that time the tick kernel and the forward.  eager: every launch issued from Python (r3's loop; A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic from profiles/ instead of two rocprofv3 counter passes in this run")
     ap.add_argument("--age-plies", type=int, default=0,
@@ -388,16 +392,28 @@ def main():
             e2.record()
             ev_tick.append((e0, e1))
             ev_net.append((e1, e2))
+            sp.ticks += 1
         else:
             sp.tick()
 
     EP_CAP = 512                                      # episodes per hand-off (~G/26 finish per step; the rest waits)
+    use_graph = args.loop == "graph"
+    SAMPLE = 8                                        # eager, event-timed ticks per step in graph mode (~2 % of a step's ticks)
 
     def run_step(target):
-        while True:
-            for _ in range(args.poll):
+        if use_graph and timing["on"]:
+            # the sample that times the two kernels: eager launches bracketed by HIP events on the launch stream, inside the
+            # timed region; everything else of the step runs from the graph
+            for _ in range(SAMPLE):
                 one_tick()
-            plies, _ = sp.progress()
+        while True:
+            if use_graph:
+                sp.run_ticks_graph(args.poll)         # returns at once
+                plies, _ = sp.progress_lagged()       # as of the previous replay: the device stays busy with the newest one
+            else:
+                for _ in range(args.poll):
+                    one_tick()
+                plies, _ = sp.progress()
             if plies >= target:
                 break
         sp.check()
@@ -411,27 +427,36 @@ def main():
         # later as ONE gather towards rank 0 (RCCL grouped send/recv over xGMI); nothing here waits for the device
         gat = afdist.EpisodeGather(world, rank, comm_dev, EP_CAP, 2 * sp.engine.KW2 + 2 * C + 2, games_per_rank=G)
 
+    handoff = {"s": 0.0, "n": 0}
+
     def collect(last=False):
+        # header-only accounting: no per-episode host work on any rank between sp.check() and the next tick
         # N = 1: the pack kernels wrote the episodes into pinned host memory one step ago
         if world == 1:
             if posted["buf"] is None:
                 return
-            eps = sp.collect_episodes(EP_CAP)
+            buf = sp.collect_episodes(EP_CAP, unpack=False)
             posted["buf"] = None
+            n_eps, n_plies = (int(buf[0]), int(buf[1])) if buf is not None else (0, 0)
         else:
-            eps = gat.flush() if last else gat.collect()
+            got = gat.flush(unpack=False) if last else gat.collect(unpack=False)
+            n_eps, n_plies = sum(p.n for p in got), sum(p.plies for p in got)
         if rank == 0:
-            gathered["episodes"] += len(eps)
-            gathered["plies"] += sum(e["T"] for e in eps)
+            gathered["episodes"] += n_eps
+            gathered["plies"] += n_plies
 
     def hand_off():
         # collect what was posted earlier (its kernels retired long ago: nothing waits), then post this step's
         # episodes behind the ticks already queued — the hand-off never sits on the tick path
+        h0 = time.perf_counter()
         collect()
         if world == 1:
             posted["buf"] = sp.post_episodes(EP_CAP)
         else:
             gat.post(sp.post_episodes_device(EP_CAP))
+        if timing["on"]:
+            handoff["s"] += time.perf_counter() - h0
+            handoff["n"] += 1
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -454,6 +479,7 @@ def main():
     p0 = sp.progress()[0]
     sp.engine.tick_histogram(stream, reset=True)
     timing["on"] = True
+    ticks0 = sp.ticks
     t0 = time.perf_counter()
     for _ in range(args.steps):
         target += G
@@ -462,6 +488,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timing["on"] = False
+    ticks_timed = sp.ticks - ticks0
     ct1 = sp.counters()
     hist = sp.engine.tick_histogram(stream)
     plies = sp.progress()[0] - p0
@@ -479,7 +506,7 @@ def main():
 
     if rank == 0:
         d = {k: ct1[k] - ct0[k] for k in ct1}
-        n_ticks = len(ev_tick)
+        n_ticks = ticks_timed                       # every tick of the timed region (graph replays + the event-timed sample)
         tick_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_tick]))
         net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net]))
         flop_pos = FLOP_PER_POSITION if cfg.board_size == 11 else net.flops_per_position()
@@ -537,10 +564,17 @@ def main():
                        "games_per_gpu": G, "sims_per_move": args.sims, "tree_value_dtype": "f64 (pipe path)" if args.pipe_values else "f32 (pv_fn path)",
                        "net_backend": roof["backend"],
                        "step": "ticks until the batch commits G more plies", "ticks_timed_rank0": n_ticks,
+                       "loop": ("HIP graph: %d x (af_tick_kernel + af_net_forward) + progress copy per replay, progress read one replay "
+                                "late; %d eager event-timed ticks per step" % (args.poll, SAMPLE)) if use_graph else
+                               ("eager: every launch issued from Python, progress poll every %d ticks" % args.poll),
+                       "ticks_event_timed_rank0": len(ev_tick),
                        "sims_per_ply_rank0": d["sims"] / max(1, d["plies"]),
                        "selects_per_sim": d["selects"] / max(1, d["sims"]),
                        "terminal_frac": d["terminals"] / max(1, d["sims"]),
-                       "episodes_gathered": gathered["episodes"], "episodes_finished_in_timed_region": int(eps_all.item())},
+                       "episodes_gathered": gathered["episodes"], "episodes_finished_in_timed_region": int(eps_all.item()),
+                       # rank 0's host time in the per-step hand-off (collect + pack launch + post), wall clock, inside the timed
+                       # region: what the other ranks would wait for at max-over-ranks timing
+                       "rank0_handoff_ms_per_step": 1e3 * handoff["s"] / max(1, handoff["n"])},
             "roofline": {"kernel": roof["kernel"], "bound": "mfma", "achieved": net_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "traffic": traffic_net, "traffic_source": traffic_src, "ms_per_launch": net_ms,
@@ -553,6 +587,8 @@ def main():
                               "peak_measured_copy": copy_gbs, "frac_of_measured_copy": tree_gbs / copy_gbs,
                               "note": "SURVEY 8d bound (HBM); PMC (profiles/r1_16) shows the kernel limited by per-game serial latency and fp64 VALU work of the noise generator"},
             "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms,
+                           # what a tick costs beyond its two kernels: launch gaps, host polls, the hand-off (<= 5 us)
+                           "outside_kernels_us_per_tick": 1e3 * (1e3 * t / max(1, n_ticks) - tick_ms - net_ms),
                            "tree_ms_max": float(np.max([a.elapsed_time(b) for a, b in ev_tick])),
                            "tree_ms_p50": float(np.median([a.elapsed_time(b) for a, b in ev_tick]))},
             "tick_shape": {"selects_per_game_and_launch_hist": hist["selects"].tolist(),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 3
+#define AF_ABI_VERSION 4
 
 /* engine modes */
 #define AF_MODE_SELFPLAY 0   /* Player.run loop on device: games restart forever (main.py:82 gen_data) */
@@ -167,6 +167,11 @@ int af_engine_set_tick_budget(af_engine* e, int32_t selects_per_launch);
 
 /* cheap progress poll (16-byte copy): out[0] = plies committed, out[1] = episodes finished */
 int af_engine_progress(af_engine* e, void* stream, uint64_t* out);
+/* ABI v4: the same 16-byte copy WITHOUT the synchronisation — `out_pinned` must be page-locked host memory (or device memory)
+ * that stays valid until the copy has run.  Stream-ordered and capturable: a driver that replays n x (tick + leaf evaluation)
+ * as one HIP graph ends the graph with this copy and reads the words after the replay's event, one replay later, so that the
+ * poll never drains the device (main.py:57-76's loop blocks on its Queue instead: the same role, without the wait). */
+int af_engine_progress_async(af_engine* e, void* stream, uint64_t* out_pinned);
 
 /* tree inspection (tests / Player.tree): nodes of game g in storage order.
  * n has the "w is fp32-typed" flag stripped into f32[]. Returns node count or <0. */
