@@ -112,6 +112,44 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Wave-wide fp64 sum with the summation tree of the tier-B specification (include/af_noise.h, oracle afo_noise_philox_dirichlet:
+// acc = acc + partner(lane ^ off) for off = 32, 16, 8, 4, 2, 1), on VALU cross-lane paths instead of six ds_bpermute round trips per
+// half: v_permlane32_swap / v_permlane16_swap (gfx950) hand every lane its own and its partner's value as the pair (r[0], r[1]) in one
+// order or the other — fp64 addition is commutative, so r[0] + r[1] has the bits of own + partner; row_ror:8 is lane ^ 8 inside a
+// 16-lane row; after that step the values are 8-periodic, so row_ror:4 delivers the value of lane ^ 4; quad permutes do ^ 2 and ^ 1.
+#ifndef AF_TICK_SUM_DPP
+#define AF_TICK_SUM_DPP 1
+#endif
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double wave_sum_f64_tree(double acc) {
+#if AF_TICK_SUM_DPP
+    {
+        const int lo = __double2loint(acc), hi = __double2hiint(acc);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        acc = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    {
+        const int lo = __double2loint(acc), hi = __double2hiint(acc);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        acc = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    acc = acc + dpp_f64<0x128>(acc);      // row_ror:8
+    acc = acc + dpp_f64<0x124>(acc);      // row_ror:4
+    acc = acc + dpp_f64<0x4E>(acc);       // quad_perm [2,3,0,1]
+    acc = acc + dpp_f64<0xB1>(acc);       // quad_perm [1,0,3,2]
+    return acc;
+#else
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+    return acc;
+#endif
+}
+
 template <int KW>
 __device__ __forceinline__ void bb_shr(const u64* a, int d, u64* o) {   // 0 < d < 64
 #pragma unroll
@@ -823,8 +861,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < KW; ++k) acc = k == 0 ? dd[0] : acc + dd[k];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+                acc = wave_sum_f64_tree(acc);
                 if (acc == 0.0) {
                     // every variate underflowed (alpha small, few legal cells; ~2^-24 per select at alpha = 0.3 and L = 1):
                     // 1/acc would make the priors NaN and the candidate set empty.  Spec (include/af_noise.h, the oracle does

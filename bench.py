@@ -177,10 +177,22 @@ def copy_bandwidth_gbs(dev, mib=1024, reps=10):
     return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def live_net_traffic(G, ticks=400, last=200, timeout_s=180):
-    """HBM bytes per net forward from the PMC counters, collected now: rocprofv3 --kernel-trace --pmc <one counter> (kernel trace
-    only, one pass per counter: MI355X_MICROARCH.md) around tools/probe_tick_min.py in a child process.  None if rocprofv3 is
-    missing or a pass fails (the caller then keeps the committed profile's figure)."""
+def _short_kernel_name(name):
+    import re
+    name = re.sub(r"\(anonymous namespace\)::", "", name.strip())
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name).replace(" >", ">")[:96]
+
+
+def live_pmc(G, ticks=400, last=200, timeout_s=180, probe="probe_tick_min.py", extra_env=None, nominal_ghz=2.4):
+    """Counters of the forward's kernels, collected now: rocprofv3 --kernel-trace --pmc <set> (kernel trace only, one pass per set:
+    MI355X_MICROARCH.md) around tools/<probe> in child processes, mean of each kernel's last `last` dispatches.
+      pass 1 / 2  FETCH_SIZE, WRITE_SIZE         -> HBM bytes per forward = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 correction
+      pass 3      GRBM_GUI_ACTIVE + SQ_VALU_MFMA_BUSY_CYCLES + the pass's own kernel durations -> per kernel: effective clock
+                  (GRBM_GUI_ACTIVE / 8 XCDs / duration), MFMA-busy share (busy cycles / (1024 SIMDs x active cycles)), MFMA FLOP/s
+                  issued (busy cycles / 32 per v_mfma_f32_32x32x16 x 32,768 FLOP / duration)
+    -> dict(traffic=bytes or None, per_kernel=[...], sustained_clock_ghz, mfma_busy) or None if rocprofv3 is missing / a pass fails
+    (the caller then keeps the committed profile's figure)."""
     import glob
     import shutil
     import sqlite3
@@ -192,13 +204,14 @@ def live_net_traffic(G, ticks=400, last=200, timeout_s=180):
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFSYS")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None
     tmp = tempfile.mkdtemp(prefix="af_pmc_", dir="/tmp")
-    per_kernel = {}
+    per_kernel, durs = {}, {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
+        for ctrs in (("FETCH_SIZE",), ("WRITE_SIZE",), ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES")):
+            d = os.path.join(tmp, ctrs[0])
             env = dict(os.environ, TICKS=str(ticks), G=str(G), TMPDIR="/tmp")
-            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable,
-                            os.path.join(REPO, "tools", "probe_tick_min.py")], cwd="/tmp", env=env, timeout=timeout_s,
+            env.update(extra_env or {})
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + list(ctrs) + ["-d", d, "-o", "p", "--", sys.executable,
+                            os.path.join(REPO, "tools", probe)], cwd="/tmp", env=env, timeout=timeout_s,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if not dbs:
@@ -208,24 +221,46 @@ def live_net_traffic(G, ticks=400, last=200, timeout_s=180):
             name_col = "kernel_name" if "kernel_name" in cols else "name"
             vals = {}
             for k, c, v in cur.execute(f"select {name_col}, counter_name, value from counters_collection order by dispatch_id"):
-                if c == ctr:
-                    vals.setdefault(k, []).append(v)
+                if c in ctrs:
+                    vals.setdefault((k, c), []).append(v)
             if not vals:
                 return None
-            for k, vs in vals.items():
-                per_kernel.setdefault(k, {})[ctr] = (sum(vs[-last:]) / len(vs[-last:]), len(vs))
+            for (k, c), vs in vals.items():
+                per_kernel.setdefault(k, {})[c] = (sum(vs[-last:]) / len(vs[-last:]), len(vs))
+            if len(ctrs) > 1:                          # durations of the same (serialised, profiled) pass
+                kcols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+                kname = "name" if "name" in kcols else "kernel_name"
+                for k, a, b in cur.execute(f"select {kname}, start, end from kernels order by start"):
+                    durs.setdefault(k, []).append(b - a)
         tick = [k for k in per_kernel if "af_tick_kernel" in k]
         if not tick or "FETCH_SIZE" not in per_kernel[tick[0]]:
             return None
         n_tick = per_kernel[tick[0]]["FETCH_SIZE"][1]
-        total = 0.0
+        total, rows, act, busy, ns, ns_all = 0.0, [], 0.0, 0.0, 0.0, 0.0
         for k, c in per_kernel.items():
-            if k in tick or "af_pack" in k or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-                continue
-            if not ("af_" in k):                       # torch fill / copy kernels of the probe's set-up
-                continue
-            total += round(c["FETCH_SIZE"][1] / n_tick) * (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0
-        return int(total) if total > 0 else None
+            if k in tick or "af_pack" in k or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or "af_" not in k:
+                continue                               # (torch fill / copy kernels of the probe's set-up)
+            per_fwd = round(c["FETCH_SIZE"][1] / n_tick)
+            total += per_fwd * (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0
+            if "GRBM_GUI_ACTIVE" in c and k in durs:
+                dn = durs[k][-last:]
+                dur = sum(dn) / len(dn)
+                a, m = c["GRBM_GUI_ACTIVE"][0] / 8.0, c.get("SQ_VALU_MFMA_BUSY_CYCLES", (0.0, 0))[0]
+                # GRBM_GUI_ACTIVE also counts the dispatch's ramp and drain outside the kernel's own timestamps: below ~50 us
+                # active / duration is not a clock (it reads > 2.4 GHz), so short kernels carry no clock and stay out of the mean
+                long_enough = dur >= 50e3
+                rows.append({"kernel": _short_kernel_name(k), "launches_per_forward": per_fwd, "us": dur / 1e3,
+                             "ghz": (a / dur) if long_enough else None,
+                             "mfma_busy": (m / (1024.0 * a)) if long_enough else None, "mfma_issued_tflops": m * 1024.0 / dur / 1e3,
+                             "hbm_mb": (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0 / 1e6})
+                if long_enough:
+                    act, busy, ns = act + per_fwd * a, busy + per_fwd * m, ns + per_fwd * dur
+                ns_all += per_fwd * dur
+        out = {"traffic": int(total) if total > 0 else None, "per_kernel": sorted(rows, key=lambda r: -r["us"]), "nominal_ghz": nominal_ghz}
+        if ns > 0:
+            out.update({"sustained_clock_ghz": act / ns, "mfma_busy": busy / (1024.0 * act),
+                        "profiled_forward_us": ns_all / 1e3, "clocked_share_of_forward": ns / ns_all})
+        return out
     except Exception:
         return None
     finally:
@@ -401,14 +436,17 @@ def main():
     SAMPLE = 8                                        # eager, event-timed ticks per step in graph mode (~2 % of a step's ticks)
 
     def run_step(target):
-        if use_graph and timing["on"]:
-            # the sample that times the two kernels: eager launches bracketed by HIP events on the launch stream, inside the
-            # timed region; everything else of the step runs from the graph
-            for _ in range(SAMPLE):
-                one_tick()
+        sample = use_graph and timing["on"]
         while True:
             if use_graph:
                 sp.run_ticks_graph(args.poll)         # returns at once
+                if sample:
+                    # the sample that times the two kernels: eager launches bracketed by HIP events on the launch stream, inside
+                    # the timed region, issued while the replay above keeps the device busy (no launch latency inside the
+                    # brackets); everything else of the step runs from the graph
+                    for _ in range(SAMPLE):
+                        one_tick()
+                    sample = False
                 plies, _ = sp.progress_lagged()       # as of the previous replay: the device stays busy with the newest one
             else:
                 for _ in range(args.poll):
@@ -520,6 +558,7 @@ def main():
         # committed counter profile of THIS round's kernels when this run is the profiled workload, else null
         traffic_net = traffic_tick = None
         traffic_src = None
+        pmc = None
         tp = os.path.join(REPO, "profiles", "r3_pmc_hbm_traffic.json")
         if not os.path.exists(tp):
             tp = os.path.join(REPO, "profiles", "r2_pmc_hbm_traffic.json")
@@ -534,9 +573,10 @@ def main():
                 # ... and, unless --no-pmc, collected again in THIS run: two short rocprofv3 counter passes over the same kernels
                 # (child processes, after the timed region; the net's traffic does not depend on the game phase, the tick
                 # kernel's does, so tree_roofline keeps the steady-state figure of the file)
-                live = None if (args.no_pmc or world > 1) else live_net_traffic(G)
-                if live is not None:
-                    traffic_net = live
+                live = None if (args.no_pmc or world > 1) else live_pmc(G)
+                if live is not None and live.get("traffic"):
+                    pmc = live
+                    traffic_net = live["traffic"]
                     traffic_src = ("this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
                                    "tools/probe_tick_min.py, bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the forward's "
                                    "kernels, mean of the last 200 dispatches; %s has %.3f GB"
@@ -604,6 +644,23 @@ def main():
             out["roofline"]["hbm_algorithmic_bytes_per_launch"] = hb
             out["roofline"]["hbm_algorithmic_gbs"] = hb / (net_ms * 1e-3) / 1e9
             out["roofline"]["hbm_frac_of_peak"] = hb / (net_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+        if pmc is not None and "sustained_clock_ghz" in pmc:
+            # what DESIGN argues from the counters, reproducible from this line alone: the chip is power-bound under this load, so the
+            # MFMA pipe's ceiling is the clock it sustains, not the nominal 2.4 GHz the 2.5 PFLOP/s peak is quoted at
+            r = out["roofline"]
+            sust_peak = peak * pmc["sustained_clock_ghz"] / pmc["nominal_ghz"]
+            r.update({"sustained_clock_ghz": pmc["sustained_clock_ghz"], "nominal_clock_ghz": pmc["nominal_ghz"],
+                      "sustained_peak_tflops": sust_peak, "mfma_busy": pmc["mfma_busy"],
+                      "frac_of_sustained_peak": r["achieved"] / sust_peak,
+                      "per_kernel": pmc["per_kernel"], "profiled_forward_us": pmc["profiled_forward_us"],
+                      "clocked_share_of_forward": pmc["clocked_share_of_forward"],
+                      "clock_source": "this run: rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES over "
+                                      "tools/probe_tick_min.py (kernels serialised by the profiler; value branch not overlapped): clock = "
+                                      "GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, time-weighted over the forward's kernels of >= 50 us "
+                                      "(clocked_share_of_forward of its time; shorter dispatches: the counter also covers ramp and drain); "
+                                      "mfma_busy = busy cycles / (1024 SIMDs x active cycles) over the same kernels"})
+            if "mfma_issued_tflops" in r:
+                r["mfma_issued_frac_of_sustained_peak"] = r["mfma_issued_tflops"] / sust_peak
         if not steady:
             out["invalid"] = ("no episode finished inside the run: this is an opening-phase rate, not the steady-state metric "
                               "(SURVEY 8d); use the defaults (--warmup 8 --steps 20)")

@@ -4,6 +4,8 @@ import glob
 import json
 import os
 
+import pytest
+
 from conftest import REPO
 
 
@@ -48,3 +50,30 @@ def test_extra_config_legs_are_flat_scalars():
         assert isinstance(d[name + "_moves_per_s"], float) and d[name + "_moves_per_s"] > 0
         assert d[name + "_episodes_finished"] > 0 and d[name + "_net_ms"] > 0 and 0 < d[name + "_mfma_frac"] < 1
     assert "15x15" in d["extra_configs"]["config4"]["metric"] and d["extra_configs"]["config5"]["dtype"] == "bf16"
+
+
+@pytest.mark.gpu
+def test_a_fresh_bench_run_prints_the_contract_line():
+    """the checks above read a committed artefact, so they pass whatever bench.py prints today.  This one runs
+    bench.py now (short: 2 timed steps on 512 games, no CPU baseline / counter passes / extra legs) and checks the line it prints."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--games", "512", "--steps", "2", "--warmup", "1", "--age-plies", "30",
+                        "--no-cpu-baseline", "--no-pmc", "--no-extra-configs"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "tree_roofline", "time_split"):
+        assert k in d, k
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["unit"] == "moves/s" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"] and "HIP graph" in d["config"]["loop"]
+    assert d["config"]["ticks_timed_rank0"] > d["config"]["ticks_event_timed_rank0"] > 0
+    r_ = d["roofline"]
+    assert r_["bound"] == "mfma" and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-9 and r_["ms_per_launch"] > 0
+    assert abs(r_["achieved"] - r_["flop_per_launch"] / (r_["ms_per_launch"] * 1e-3) / 1e12) < 1e-6 * r_["achieved"]
+    plies = d["ms_per_step"] * 1e-3 * d["steps"] * (d["value"] or d["opening_phase_moves_per_s"])
+    assert abs(plies - 2 * 512) < 0.25 * 2 * 512                 # a step commits about one ply per game
+    assert "rank0_handoff_ms_per_step" in d["config"] and d["config"]["rank0_handoff_ms_per_step"] < 5.0
+    assert abs(d["time_split"]["outside_kernels_us_per_tick"]) < 100
