@@ -21,6 +21,8 @@
 // per position a workgroup reads 36 KB (+36 KB PROJ) and writes 31 KB of HBM: 8192 positions x 16 convolutions
 // = 4.7 TFLOP and ~11 GB per tower pass, i.e. MFMA-bound (1.9 ms) over HBM (1.4 ms at 8 TB/s) by a small margin.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 #include <string.h>
 
@@ -92,6 +94,7 @@ struct TowerArgs {
     char* out;           // C8 bf16
     int batch;
     int abl;             // profiling: bit 0 = stage only the first position, bit 1 = no stores, bit 2 = no ELU
+    char* dump;          // af_tower_conv3: 4 KB the lanes past the board store to (an unconditional store keeps the epilogue out of a branch)
 };
 
 constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;                    // 13 rows x 11 pixels (+1): pixel n sits at unit n + 11
@@ -243,6 +246,199 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
                 if (ok[j] && !(A.abl & 2)) *reinterpret_cast<bf16x8*>(o + (uint32_t)((4 * wv + 2 * kg + hf) * kPIX) * 16u + ob[j]) = v;
             }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// af_tower_conv3<PROJ, DEPTH> (r4): af_tower_conv with its epilogue taken off the critical path.  In af_tower_conv a position is
+// 288 [320] MFMAs over FOUR live accumulator sets (pixel tile = MFMA index mod 4) followed by ~300 VALU instructions of bias / ELU /
+// bf16 / stores during which the matrix pipe idles (one wave per SIMD: nobody else can use it) — 0.65 of 4.2 ms per tower pass.
+// Here the position runs as two PHASES of two pixel tiles each (tiles 0,1 then tiles 2,3: 144 [160] MFMAs per phase, still alternating
+// accumulators), and the finished pair's epilogue is issued in 48 small pieces (a third of a two-element chunk: 3-5 VALU) inside the OTHER pair's MFMA
+// stream — pair A's under phase B of the same position, pair B's under phase A of the next one — where a wave's VALU work costs a
+// fraction of its serial price (tools/probes/mfma_valu_coissue.hip: 4 VALU per MFMA add ~7 cycles to its 32).  Live accumulators:
+// the accumulating pair + the pair in its epilogue = the same 64 registers as before.
+// PROJ: the 16 projection MFMAs of a phase sit at the END of phase A and at the START of phase B, so the single-buffered block-input
+// plane is needed for one 32-MFMA window in the middle of a position and the next position's copy of it streams in behind that
+// window (9 pieces, one every 16 MFMAs) with 144 MFMAs to land.  Same MFMAs on the same operands in the same per-accumulator order
+// as af_tower_conv (k-steps ascending per tile; PROJ: projection steps last for tiles 0,1 and first for tiles 2,3 — af_tower_conv
+// runs them first for all four), so tiles 2,3 of the PROJ layers and every tile of the others are bit-identical to af_tower_conv.
+template <bool PROJ, int DEPTH>
+__global__ __launch_bounds__(256, 1) void af_tower_conv3(TowerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // [256 B][g0][g1]([h])
+    constexpr int NS = PROJ ? 80 : 72;
+    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem + kLds0;
+
+    auto stage_round = [&](const char* src, int pos, uint32_t off, int r) {   // 4 KB piece r of a position's plane -> LDS
+        glds16(src + (size_t)pos * kPlaneB + threadIdx.x * 16u + r * 4096,
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + off + wv * 1024u + r * 4096u)));
+    };
+    int pos = blockIdx.x;
+    if (pos >= A.batch) return;
+    constexpr uint32_t kZoff = kLds0 + (PROJ ? 3u : 2u) * kPlaneB;      // the zero region follows the planes
+    for (uint32_t u = threadIdx.x; u < kZeroB / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) stage_round(A.in, pos, 0u, r);
+    if (PROJ) {
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) stage_round(A.in2, pos, 2u * kPlaneB, r);
+    }
+    bf16x8 W[NS];
+    {
+        const uint4* wp = A.w + ((size_t)wv * NS * 64 + lane);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint4 v = wp[s * 64];
+            __builtin_memcpy(&W[s], &v, 16);
+        }
+    }
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = A.bias[32 * wv + 16 * kg + r];
+    uint32_t lb[4], ob[4], zb[4];
+    bool ok[4], edgeL[4], edgeR[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = 32 * j + nn;
+        ok[j] = n < kNPIX;
+        const int nc = ok[j] ? n : 0;
+        const int x = nc % kS;
+        edgeL[j] = x == 0; edgeR[j] = x == kS - 1;
+        lb[j] = kLds0 + (uint32_t)(kg * kPIX + nc + kS - (kS + 1)) * 16u;
+        ob[j] = (uint32_t)(nc + kS) * 16u;
+        zb[j] = kZoff + (lb[j] & 255u);
+    }
+    constexpr int kNVfit = (256 - 4 * DEPTH - AF_TOWER_VSLACK) / 4, kNVmin = NS - (256 - 64) / 4;
+    constexpr int NV = kNVfit > kNVmin ? kNVfit : kNVmin;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s < NV) asm volatile("" : "+v"(W[s]));
+        else asm volatile("" : "+a"(W[s]));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bias_r[r]));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // MFMA m of a position -> (pixel tile j, projection step?, k-step index): phase A = m < NH (tiles 0,1), phase B = tiles 2,3
+    constexpr int NM = NS * 4, NH = NM / 2, NP = PROJ ? 16 : 0;          // per phase: NH MFMAs of which NP are projection steps
+    struct MI { int j, proj, s; };
+    auto mi = [](int m) constexpr -> MI {
+        constexpr int NM_ = (PROJ ? 80 : 72) * 4, NH_ = NM_ / 2, NP_ = PROJ ? 16 : 0;
+        const int ph = m >= NH_, q = m - ph * NH_, j = 2 * ph + (q & 1);
+        // phase A: 144 3x3 steps then NP projection steps; phase B: NP projection steps then 144 3x3 steps
+        const bool proj = ph ? q < NP_ : q >= NH_ - NP_;
+        const int s = proj ? (ph ? q : q - (NH_ - NP_)) >> 1 : (ph ? q - NP_ : q) >> 1;
+        return MI{j, proj ? 1 : 0, s};
+    };
+    f32x16 acc[4];
+    const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    char* o_prev = nullptr;
+
+    // epilogue of pixel-tile pair jp0 as 16 chunks (tile jp0 + (c >> 3), elements 2*(c & 7), +1) of three stages of 3-5 VALU
+    // instructions each — bias + scale | exp2 + clamp - 1 | max, bf16 (+ a 16-byte store after every fourth chunk) — so that one stage
+    // fits the shadow of one MFMA; stage k of chunk c is issued behind MFMA 2*(3c + k) + 3 of the phase, fenced so that hipcc keeps it
+    // there (unfenced it gathers four chunks in front of their store and reads a whole accumulator set in one burst)
+    bf16x8 vst;
+    f32x2 ex_[16], et_[16];
+    auto epi_stage = [&](int jp0, int c, int k, char* o) {
+        const int j = jp0 + (c >> 3), q = c & 7, hf = q >> 2, e = 2 * (q & 3);
+        if (k == 0) {
+            // (read where they are used: left to itself hipcc copies the whole finished accumulator set out of the accumulator
+            // registers in one burst of 32 v_accvgpr_read at the top of the phase)
+            float a0, a1;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a0) : "a"(acc[j][8 * hf + e]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a1) : "a"(acc[j][8 * hf + e + 1]));
+            ex_[c] = f32x2{a0, a1} + f32x2{bias_r[8 * hf + e], bias_r[8 * hf + e + 1]};
+            et_[c] = ex_[c] * 1.44269504088896341f;
+        } else if (k == 1) {
+            f32x2 ee;
+            ee.x = fminf(fmaxf(__builtin_amdgcn_exp2f(et_[c].x), 0.0f), 1.0f);
+            ee.y = fminf(fmaxf(__builtin_amdgcn_exp2f(et_[c].y), 0.0f), 1.0f);
+            et_[c] = ee - 1.0f;
+        } else {
+            vst[e] = (__bf16)fmaxf(ex_[c].x, et_[c].x); vst[e + 1] = (__bf16)fmaxf(ex_[c].y, et_[c].y);
+            if ((q & 3) == 3) {
+                char* dst = o + (uint32_t)((4 * wv + 2 * kg + hf) * kPIX) * 16u + ob[j];
+                if (j == 3) dst = ok[3] ? dst : A.dump + threadIdx.x * 16u;        // (only tile 3 has lanes past the board)
+                *reinterpret_cast<bf16x8*>(dst) = vst;
+            }
+        }
+    };
+
+    auto position = [&](auto first_tag, int it, int pos_) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint32_t gcur = (it & 1) ? kPlaneB : 0u, gnxt = kPlaneB - gcur;
+        const int nxt = pos_ + (int)gridDim.x;
+        const bool more = nxt < A.batch && !(A.abl & 1);
+        char* const o = A.out + (size_t)pos_ * kPlaneB;
+        uint32_t bC[4], bL[4], bR[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bC[j] = (AF_TOWER_ZPAD && !ok[j]) ? zb[j] : gcur + lb[j];
+            bL[j] = edgeL[j] ? zb[j] : bC[j];
+            bR[j] = edgeR[j] ? zb[j] : bC[j];
+        }
+        auto rd = [&](int m) -> bf16x8 {
+            const MI x = mi(m);
+            if (x.proj) return *reinterpret_cast<const bf16x8*>(smem + 2u * kPlaneB + lb[x.j] + (uint32_t)(2 * x.s * kPIX + kS + 1) * 16u);
+            const int t = x.s >> 3, cc = x.s & 7;
+            const uint32_t base = t % 3 == 0 ? bL[x.j] : (t % 3 == 2 ? bR[x.j] : bC[x.j]);
+            return *reinterpret_cast<const bf16x8*>(smem + base + (uint32_t)(2 * cc * kPIX + (t / 3) * kS + (t % 3)) * 16u);
+        };
+        bf16x8 ring[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) ring[i] = rd(i);
+#pragma clang loop unroll(full)
+        for (int m = 0; m < NM; ++m) {
+            const MI x = mi(m);
+            const int ws = x.proj ? 72 + x.s : x.s;
+            // the first MFMA of a tile starts from zero: the accumulator is not cleared while the pair is still in its epilogue
+            // (srcC = the constant 0: the accumulator registers are not touched before this MFMA writes them)
+            const bool fresh = (m < NH ? m : m - NH) < 2;
+            if (fresh) acc[x.j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[ws], ring[m % DEPTH], kZero16, 0, 0, 0);
+            else acc[x.j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[ws], ring[m % DEPTH], acc[x.j], 0, 0, 0);
+            if (m + DEPTH < NM && !AF_TOWER_ABL_NOLDS) ring[m % DEPTH] = rd(m + DEPTH);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            // the other pair's epilogue, one chunk every 8 MFMAs from the 5th on (16 chunks inside the phase's first 132 MFMAs)
+            {
+                const int q = m < NH ? m : m - NH;
+                if (q >= 3 && (q - 3) % 2 == 0 && (q - 3) / 2 < 48 && (m >= NH || !FIRST)) {
+                    const int st_ = (q - 3) / 2;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m >= NH) epi_stage(0, st_ / 3, st_ % 3, o);                // pair A of this position, under phase B
+                    else epi_stage(2, st_ / 3, st_ % 3, o_prev);                   // pair B of the previous position, under phase A
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the next position's planes: one 4 KB piece every 16 MFMAs from the start of the position
+            if (m % 16 == 0 && m / 16 < kRounds && more) stage_round(A.in, nxt, gnxt, m / 16);
+            if (PROJ) {
+                constexpr int kAfter = NH + NP;                  // first MFMA after the projection window
+                if (m == kAfter - 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();                // every wave is done with the block-input plane
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (m >= kAfter && (m - kAfter) % 16 == 8 && (m - kAfter) / 16 < kRounds && more)
+                    stage_round(A.in2, nxt, 2u * kPlaneB, (m - kAfter) / 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the next position's planes have landed ...
+        __builtin_amdgcn_s_barrier();                                   // ... for every wave, and all are done with this one
+        o_prev = o;
+    };
+
+    position(std::true_type{}, 0, pos);
+    pos += gridDim.x;
+    for (int it = 1; pos < A.batch; pos += gridDim.x, ++it) position(std::false_type{}, it, pos);
+    // the last position's second pair
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) epi_stage(2, c, k, o_prev);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -725,6 +921,7 @@ struct af_tower {
     std::vector<float*> b1, b2;
     std::vector<char> set;
     uint4* stem_w = nullptr;
+    char* dump = nullptr;
     float* stem_b = nullptr;
     float* heads_w = nullptr;
     float* heads_b = nullptr;
@@ -836,8 +1033,11 @@ int af_tower_create(int32_t S, int32_t width, int32_t blocks, int32_t device, af
 #define TW_ATTR(P, D) TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv<P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     TW_ATTR(false, 8); TW_ATTR(true, 8); TW_ATTR(false, 12); TW_ATTR(true, 12); TW_ATTR(false, 16); TW_ATTR(true, 16);
 #undef TW_ATTR
+    TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv3<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv3<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    { void* q = nullptr; TW_HIP_OK(hipMalloc(&q, 4096)); t->dump = static_cast<char*>(q); }
     *out = t;
     return AF_TOWER_OK;
 }
@@ -852,6 +1052,7 @@ void af_tower_destroy(af_tower* t) {
     for (auto p : t->b1) if (p) (void)hipFree(p);
     for (auto p : t->b2) if (p) (void)hipFree(p);
     if (t->stem_w) (void)hipFree(t->stem_w);
+    if (t->dump) (void)hipFree(t->dump);
     if (t->stem_b) (void)hipFree(t->stem_b);
     if (t->heads_w) (void)hipFree(t->heads_w);
     if (t->heads_b) (void)hipFree(t->heads_b);
@@ -997,7 +1198,7 @@ int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_
     const int grid = batch < ncu ? batch : ncu;
     for (int b = 0; b < t->blocks; ++b) {
         TowerArgs a;
-        a.batch = batch; a.abl = g_abl;
+        a.batch = batch; a.abl = g_abl; a.dump = t->dump;
         const char* xin = static_cast<const char*>(x_dev);
         if (g_engine == 1) {
             const int gx = batch < ncu / 2 ? batch : ncu / 2;
@@ -1011,6 +1212,13 @@ int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_
         // ring depth per kernel: the deepest that hipcc allocates without scratch (a scratch reload's vmcnt(0) would
         // also wait for the LDS-DMA of the next position: measured 400 vs 230 us per launch)
         const int d1 = g_depth ? g_depth : 12, d2 = g_depth ? g_depth : 8;
+        if (g_engine == 2) {     // r4: epilogue overlapped with the other tile pair's MFMAs
+            hipLaunchKernelGGL((af_tower_conv3<false, 8>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);
+            a.in = static_cast<const char*>(g_dev); a.in2 = xin; a.w = t->w2[b]; a.bias = t->b2[b];
+            a.out = static_cast<char*>(x_dev);
+            hipLaunchKernelGGL((af_tower_conv3<true, 8>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, a);
+            continue;
+        }
         if (d1 == 16) hipLaunchKernelGGL((af_tower_conv<false, 16>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);
         else if (d1 == 12) hipLaunchKernelGGL((af_tower_conv<false, 12>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);
         else hipLaunchKernelGGL((af_tower_conv<false, 8>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);

@@ -509,10 +509,12 @@ def main():
             target += G
             run_step(target)
         sp.engine.set_simulations(args.sims, args.upper)
+        target = sp.progress()[0]                     # (the lagged poll lets a phase overshoot its last target: start from the truth)
     for _ in range(args.warmup):
         target += G
         run_step(target)
     barrier()
+    target = sp.progress()[0]
     ct0 = sp.counters()
     p0 = sp.progress()[0]
     sp.engine.tick_histogram(stream, reset=True)
