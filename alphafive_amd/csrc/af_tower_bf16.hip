@@ -999,8 +999,10 @@ static int upload(T** dst, const void* src, size_t bytes) {
 static int g_depth = 0;     // B-fragment ring depth (A/B knob; 0 = per-kernel default)
 static int g_abl = 0;       // profiling ablations (results wrong by design)
 static int g_grid = 0;      // persistent workgroups (0 = one per CU)
-static int g_engine = 0;    // 0: af_tower_conv (default: 5.11 ms per 8192-position tower pass); 1: af_tower_conv2 (r2 experiment: 5.37 ms — its
-                            // 32-channel slabs give a wave only 36 MFMAs between barriers; same 3.8 ms floor without staging and stores)
+static int g_engine = 3;    // 3 (default, r4): af_tower_conv3 for a block's first convolution + af_tower_conv for its second (bit-identical to 0,
+                            //    4.143 vs 4.167 ms per 8192-position tower pass); 0: af_tower_conv for both; 2: af_tower_conv3 for both (its
+                            //    PROJ form is slower: 4.224 ms); 1: af_tower_conv2 (r2 experiment: 5.37 ms — its 32-channel slabs give a
+                            //    wave only 36 MFMAs between barriers; same 3.8 ms floor without staging and stores)
 
 extern "C" {
 
@@ -1212,11 +1214,12 @@ int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_
         // ring depth per kernel: the deepest that hipcc allocates without scratch (a scratch reload's vmcnt(0) would
         // also wait for the LDS-DMA of the next position: measured 400 vs 230 us per launch)
         const int d1 = g_depth ? g_depth : 12, d2 = g_depth ? g_depth : 8;
-        if (g_engine == 2) {     // r4: epilogue overlapped with the other tile pair's MFMAs
+        if (g_engine == 2 || g_engine == 3) {     // r4: epilogue overlapped with the other tile pair's MFMAs (3: first convolution only)
             hipLaunchKernelGGL((af_tower_conv3<false, 8>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);
             a.in = static_cast<const char*>(g_dev); a.in2 = xin; a.w = t->w2[b]; a.bias = t->b2[b];
             a.out = static_cast<char*>(x_dev);
-            hipLaunchKernelGGL((af_tower_conv3<true, 8>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, a);
+            if (g_engine == 2) hipLaunchKernelGGL((af_tower_conv3<true, 8>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, a);
+            else hipLaunchKernelGGL((af_tower_conv<true, 8>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, a);
             continue;
         }
         if (d1 == 16) hipLaunchKernelGGL((af_tower_conv<false, 16>), dim3(grid), dim3(256), kLds0 + 2 * kPlaneB + kZeroB, st, a);

@@ -351,16 +351,21 @@ def test_deep_bf16_tower_kernel_matches_fp32_reference(blocks):
     tw.load_nchw(h0)                                 # a second pass reproduces the result bit for bit
     tw.forward(B)
     assert torch.equal(tw.store_nchw(B).float(), out)
-    from alphafive_amd import tower_hip              # the alternative convolution kernel (af_tower_tune key 3) meets the same bar
-    try:
-        tower_hip.tune(3, 1)
-        tw.load_nchw(h0)
-        tw.forward(B)
-        out2 = tw.store_nchw(B).float()
-    finally:
-        tower_hip.tune(3, 0)
-    err2 = (out2 - ref).abs()
-    assert err2.mean().item() <= 1.1 * err_torch.mean().item() + 1e-4 and err2.max().item() <= 2.0 * err_torch.max().item() + 0.02
+    from alphafive_amd import tower_hip              # the other convolution kernels (af_tower_tune key 3) meet the same bar
+    for engine in (0, 1, 2):                         # 0 af_tower_conv for both convolutions, 1 af_tower_conv2, 2 af_tower_conv3 for both
+        try:
+            tower_hip.tune(3, engine)
+            tw.load_nchw(h0)
+            tw.forward(B)
+            out2 = tw.store_nchw(B).float()
+        finally:
+            tower_hip.tune(3, 3)
+        err2 = (out2 - ref).abs()
+        assert err2.mean().item() <= 1.1 * err_torch.mean().item() + 1e-4 and err2.max().item() <= 2.0 * err_torch.max().item() + 0.02, engine
+        if engine == 0:                              # the default (conv3 for the first convolution of a block) changes no bit
+            assert torch.equal(out2, out)
+        for buf in (tw.x, tw.g):
+            assert float(buf[:, :, :S].float().abs().sum()) == 0.0 and float(buf[:, :, S + S * S:].float().abs().sum()) == 0.0
     x = torch.from_numpy(_rand_planes(B, 11, seed=2)).cuda()
     # stem kernel and heads' 1x1-conv kernel vs fp32 PyTorch ops on the same (bf16-valued) weights and inputs
     net.stem = (net.stem[0], (torch.randn(128, generator=g) * 0.1).to("cuda", torch.bfloat16))

@@ -59,4 +59,4 @@ flop = 2 * 8 * (128 * 128 * 9 * 2 + 128 * 128) * 121 * B
 for e in ENG:
     ms = min(res[e])
     print("engine %d: tower pass %.3f ms (rounds: %s) = %.0f TFLOP/s = %.3f of the 2.5 PFLOP/s bf16 peak" % (e, ms, " ".join("%.3f" % x for x in res[e]), flop / ms / 1e9, flop / ms / 1e9 / 2500))
-tower_hip.tune(3, 0)
+tower_hip.tune(3, 3)
