@@ -120,6 +120,9 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 #ifndef AF_TICK_SUM_DPP
 #define AF_TICK_SUM_DPP 1
 #endif
+#ifndef AF_TICK_NOISE_PASS0
+#define AF_TICK_NOISE_PASS0 1
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -349,7 +352,7 @@ __device__ float pairwise_sum(const float* a, int n) {   // n <= 256
 // profiling build only (tools/probe_tick_timing.py): shader cycles of the last launch per game and phase —
 // 0 state load, 1 consume (expand + backup), 2 move boundary (calc_policy, record, collector), 3 terminal test + store lookup,
 // 4 select (rows, noise, score, argmax, step), 5 park / yield + state store, 6 total, 7 selects
-__device__ unsigned long long g_tick_cycles[8192][8];
+__device__ unsigned long long g_tick_cycles[8192][13];      // 8..11: inside the select: rows + noise rounds | noise sum + normalise | scores | argmax, pick, prefetch, step
 #define TK_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define TK_ACC(slot, a, b) tk[slot] += (b) - (a)
 #else
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     if (phase == PH_IDLE || phase == PH_MOVE_DONE || phase == PH_ERROR) return;
     const u64 t_start = wall_clock64();
 #ifdef AF_TICK_TIMING
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // 12: rejection-loop iterations
 #endif
     TK_T(tk_entry);
 
@@ -832,15 +835,70 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 // a lane draws its KW cells in ONE rejection loop (the wave leaves it when the slowest lane has
                 // all its variates; the rounds of a cell are indexed by the counter, so the values are those
                 // of af_gamma_lt1 cell by cell)
+#ifdef AF_TICK_TIMING
+                int tk_myit = 0;
+#endif
                 {
                     const float a_ = (float)P.alpha, inv_a = 1.0f / a_, one_m_a = 1.0f - a_;
                     uint32_t todo = 0;
 #pragma unroll
                     for (int k = 0; k < KW; ++k) { dd[k] = 0.0; todo |= ((legal[k] >> lane) & 1ull) ? (1u << k) : 0u; }
+#if AF_TICK_NOISE_PASS0
+                    // Round 0 of EVERY cell of the lane first, side by side (two independent dependency chains: the kernel's slow
+                    // waves run alone on their SIMD and wait on instruction latency, not on issue slots), then the rejected cells
+                    // (10 % of them) one at a time as before: the wave needs 1 double + ~2 single rounds instead of ~4 singles, at the
+                    // same instruction count.  (Both cells side by side in every round costs twice the instructions in the clean-up
+                    // rounds, where most lanes idle: +7 % per launch, profiles/r4_07.)  The rounds of a cell are indexed by its own
+                    // counter, so every variate is the one af_gamma_lt1 returns.
+                    af_u32x4 rk[KW];
+                    uint32_t pend = 0;
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) {
+                        rk[k] = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * k), 0u, k0, k1);
+                        float X;
+                        const int ok = af_gamma_round(a_, inv_a, one_m_a, rk[k].v[0], rk[k].v[1], &X);
+                        const bool lg = (todo >> k) & 1u;
+                        dd[k] = (lg && ok) ? (double)X : 0.0;
+                        pend |= (lg && !ok) ? (1u << k) : 0u;
+                        if (KW > 2 && (k & 1)) __builtin_amdgcn_sched_barrier(0);      // (15x15: two chains at a time, not four)
+                    }
+#ifdef AF_TICK_TIMING
+                    ++tk_myit;
+#endif
+                    todo = pend;
+                    uint32_t it = 1;
+                    af_u32x4 r = rk[0];
+#pragma unroll
+                    for (int q = 1; q < KW; ++q) if (!(todo & ((1u << q) - 1u))) r = rk[q];       // the first pending cell's block
+                    while (todo) {
+#ifdef AF_TICK_TIMING
+                        ++tk_myit;
+#endif
+                        const int k = __builtin_ctz(todo);
+                        if ((it & 1u) == 0u) r = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * k), it >> 1, k0, k1);
+                        const uint32_t wu = (it & 1u) ? r.v[2] : r.v[0], wv = (it & 1u) ? r.v[3] : r.v[1];
+                        float X;
+                        const int ok = af_gamma_round(a_, inv_a, one_m_a, wu, wv, &X);
+                        if (ok || it == 0xFFFFu) {
+                            const double Xd = ok ? (double)X : 0.0;
+#pragma unroll
+                            for (int q = 0; q < KW; ++q) dd[q] = q == k ? Xd : dd[q];
+                            todo &= todo - 1u;
+                            it = 1;
+#pragma unroll
+                            for (int q = 1; q < KW; ++q) if (todo && !(todo & ((1u << q) - 1u))) r = rk[q];
+                        } else {
+                            ++it;
+                        }
+                    }
+#else
                     uint32_t it = 0;
                     af_u32x4 r;
                     r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
                     while (todo) {
+#ifdef AF_TICK_TIMING
+                        ++tk_myit;
+#endif
                         const int k = __builtin_ctz(todo);
                         // one Philox block feeds two rounds of a cell (a lane stays on its cell until it accepts)
                         if ((it & 1u) == 0u) r = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * k), it >> 1, k0, k1);
@@ -857,7 +915,13 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                             ++it;
                         }
                     }
+#endif
                 }
+#ifdef AF_TICK_TIMING
+                tk[12] += (unsigned long long)wave_max_i32(tk_myit);       // the wave's iterations = its slowest lane's
+#endif
+                TK_T(tk_n1);
+                TK_ACC(8, tk_b, tk_n1);
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < KW; ++k) acc = k == 0 ? dd[0] : acc + dd[k];
@@ -877,7 +941,10 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
 #pragma unroll
                     for (int k = 0; k < KW; ++k) dd[k] = dd[k] * inv;
                 }
+                TK_T(tk_n1e);
+                TK_ACC(9, tk_n1, tk_n1e);
             }
+            TK_T(tk_n2);
             const double sq = sqrt((double)(sum_n + 1));
             float sc[KW];
             float mx = -3.0e38f;
@@ -900,6 +967,8 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 sc[k] = lg ? (float)(q64 + t) : -3.0e38f;
                 mx = sc[k] > mx ? sc[k] : mx;
             }
+            TK_T(tk_n3);
+            TK_ACC(10, tk_n2, tk_n3);
             int cell = -1;
             if (is_root && P.training) {                                    // :264-276 forced root visits
                 u64 cand[KW];
@@ -958,6 +1027,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             __syncthreads();
             TK_T(tk_c);
             TK_ACC(4, tk_b, tk_c);
+            TK_ACC(11, tk_n3, tk_c);
 #ifdef AF_TICK_TIMING
             tk[7] += 1;
 #endif
@@ -996,7 +1066,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         TK_T(tk_end);
         tk[5] = tk_end - tk_parked;
         tk[6] = tk_end - tk_entry;
-        if (lane == 0 && g < 8192) for (int q = 0; q < 8; ++q) g_tick_cycles[g][q] = tk[q];
+        if (lane == 0 && g < 8192) for (int q = 0; q < 13; ++q) g_tick_cycles[g][q] = tk[q];
     }
 #endif
 }
@@ -1689,7 +1759,7 @@ int af_engine_set_tree_w64(af_engine* e, int32_t game, int32_t count, const doub
 #ifdef AF_TICK_TIMING
 int af_engine_debug_tick_cycles(unsigned long long* host) {
     HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tick_cycles), sizeof(unsigned long long) * 8192 * 8));
+    HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tick_cycles), sizeof(unsigned long long) * 8192 * 13));
     return AF_OK;
 }
 #endif

@@ -150,13 +150,17 @@ AF_HD uint32_t af_f2bits(float f) { union { uint32_t u; float f; } x; x.f = f; r
 
 #define AF_NEG_HUGE_F (-1.0e30f)
 
-/* natural log of a positive normal float; af_logf(x <= 0) = AF_NEG_HUGE_F (arguments here are >= 2^-24) */
+/* natural log of a positive normal float; af_logf(x <= 0) = AF_NEG_HUGE_F (arguments here are >= 2^-24).
+ * Straight-line code (r4): the x <= 0 case is a select at the end, not an early return — on the GPU an early return is a divergent
+ * branch (exec-mask save / restore) in front of every log of every rejection round, and it fences the two independent logs of a
+ * round (V and Y) off from each other; the arithmetic and so every result bit is unchanged. */
 AF_HD float af_logf(float x) {
-    if (!(x > 0.0f)) return AF_NEG_HUGE_F;
     const uint32_t b = af_f2bits(x);
     int e = (int)(b >> 23) - 127;
     float m = af_bits2f((b & 0x007FFFFFu) | 0x3F800000u);      /* [1,2) */
-    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }              /* [0.7071,1.4142] */
+    const int up = m > 1.41421356f;                             /* -> [0.7071,1.4142] */
+    m = up ? m * 0.5f : m;
+    e += up;
     const float f = m - 1.0f;
     const float s = f / (2.0f + f);
     const float z = s * s;
@@ -167,23 +171,24 @@ AF_HD float af_logf(float x) {
     const float hfsq = 0.5f * f * f;
     const float dk = (float)e;
     const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
-    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    const float r = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    return (x > 0.0f) ? r : AF_NEG_HUGE_F;
 }
 
-/* exp(x); 0 below -87, saturates above 88 */
+/* exp(x); 0 below -87, saturates above 88 (straight-line like af_logf: the argument is clamped, the underflow case selected at the end) */
 AF_HD float af_expf(float x) {
-    if (x < -87.0f) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
+    const float xc = x > 88.0f ? 88.0f : (x < -87.0f ? -87.0f : x);
     const float inv_ln2 = 1.4426950216e+00f, ln2_hi = 6.9314575195e-01f, ln2_lo = 1.4286067653e-06f;
-    const float kf = x * inv_ln2;
+    const float kf = xc * inv_ln2;
     const int k = (int)(kf + (kf < 0.0f ? -0.5f : 0.5f));
     const float dk = (float)k;
-    const float hi = x - dk * ln2_hi, lo = dk * ln2_lo;
+    const float hi = xc - dk * ln2_hi, lo = dk * ln2_lo;
     const float r = hi - lo;
     const float t = r * r;
     const float c = r - t * (1.6666625440e-01f + t * -2.7667332906e-03f);
     const float y = 1.0f - ((lo - (r * c) / (2.0f - c)) - hi);
-    return y * af_bits2f((uint32_t)(k + 127) << 23);            /* k in [-126, 127] */
+    const float v = y * af_bits2f((uint32_t)(k + 127) << 23);   /* k in [-126, 127] */
+    return x < -87.0f ? 0.0f : v;
 }
 
 /* 24-bit uniform in [0, 1 - 2^-24] from one word */

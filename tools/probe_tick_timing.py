@@ -24,11 +24,12 @@ sp = SelfPlayEngine(cfg, G, net.select_backend("hip"), seed=0)
 sp.run_ticks(int(os.environ.get("TICKS", 2500)))
 L = eng.lib()
 L.af_engine_debug_tick_cycles.argtypes = [C.POINTER(C.c_uint64)]
-names = ["state load", "consume (expand + backup)", "move boundary", "terminal test + lookup", "select", "park + state store", "total", "selects"]
-acc = np.zeros((0, 8))
+names = ["state load", "consume (expand + backup)", "move boundary", "terminal test + lookup", "select", "park + state store", "total", "selects",
+         "  select: rows + noise rounds", "  select: noise sum + normalise", "  select: scores", "  select: argmax, pick, prefetch, step"]
+acc = np.zeros((0, 13))
 for _ in range(int(os.environ.get("SAMPLES", 40))):
     sp.run_ticks(7)
-    buf = np.zeros((8192, 8), np.uint64)
+    buf = np.zeros((8192, 13), np.uint64)
     assert L.af_engine_debug_tick_cycles(buf.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
     acc = np.concatenate([acc, buf[:G].astype(np.float64)])
 tot = acc[:, 6]
@@ -36,5 +37,9 @@ print("waves sampled %d; mean total %.0f cycles, p50 %.0f, p99 %.0f, max %.0f; s
 for q in range(6):
     print("  %-28s %6.1f %% of wave cycles  (mean %.0f cycles per launch%s)" % (names[q], 100 * acc[:, q].sum() / tot.sum(), acc[:, q].mean(),
           (", %.0f per select" % (acc[:, q].sum() / acc[:, 7].sum())) if q in (3, 4) else ""))
+for q in range(8, 12):
+    print("  %-40s %6.1f %% of wave cycles  (%.0f cycles per select)" % (names[q], 100 * acc[:, q].sum() / tot.sum(), acc[:, q].sum() / acc[:, 7].sum()))
+print("  rejection-loop iterations of a wave per select: %.2f (every lane draws its 2 cells one after the other: the wave runs until its slowest lane has both)" % (acc[:, 12].sum() / acc[:, 7].sum()))
 slow = acc[tot >= np.percentile(tot, 99)]
-print("slowest 1 %% of waves: selects %.1f; shares: " % slow[:, 7].mean() + ", ".join("%s %.0f %%" % (names[q], 100 * slow[:, q].sum() / slow[:, 6].sum()) for q in range(6)))
+print("slowest 1 %% of waves: selects %.1f, %.0f cycles; shares: " % (slow[:, 7].mean(), slow[:, 6].mean()) + ", ".join("%s %.0f %%" % (names[q].strip(), 100 * slow[:, q].sum() / slow[:, 6].sum()) for q in list(range(6)) + list(range(8, 12))))
+print("slowest 1 %%: cycles per select: " + ", ".join("%s %.0f" % (names[q].strip(), slow[:, q].sum() / slow[:, 7].sum()) for q in (3, 4, 8, 9, 10, 11)))
