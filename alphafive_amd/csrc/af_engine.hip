@@ -123,6 +123,9 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 #ifndef AF_TICK_NOISE_PASS0
 #define AF_TICK_NOISE_PASS0 1
 #endif
+#ifndef AF_TICK_TERM_LAST
+#define AF_TICK_TERM_LAST 1
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -190,6 +193,21 @@ __device__ __forceinline__ int bb_select(const u64* a, int r) {   // index of th
         r -= pc;
     }
     return -1;
+}
+// The same on the lanes (r4): lane l asks "is bit l of word k set and are exactly r bits set below it?" — v_mbcnt counts a mask's
+// bits below the lane — and a ballot names the one lane that says yes.  The scalar loop above clears r bits one by one: ~5 SALU
+// instructions per bit, and a forced root visit (player.py:264-276, half of all root selects) picks among up to 121 candidates.
+template <int KW>
+__device__ __forceinline__ int bb_select_wave(const u64* a, int r, int lane) {   // a and r wave-uniform; -1 if r >= popcount
+    int base = 0, out = -1;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(a[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)a[k], 0u));
+        const u64 hit = __ballot(((a[k] >> lane) & 1ull) && base + below == r);
+        if (hit) out = 64 * k + __builtin_ctzll(hit);
+        base += __popcll(a[k]);
+    }
+    return out;
 }
 template <int KW>
 __device__ __forceinline__ bool bb_test(const u64* a, int c) {
@@ -265,6 +283,37 @@ __device__ int terminal_test(const EngineParams& P, const u64* mine, const u64* 
         }
     }
     if (best_key != 0x7fffffff) { *value = best_v; return 1; }
+    bool full = true;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) full = full && ((mine[k] | theirs[k]) == P.boardmask[k]);
+    *value = 0.0f;
+    return full ? 1 : 0;
+}
+
+// The same test inside a descent (depth > 0), where the position was reached by playing `last` from a position that was NOT
+// terminal: a line can only have been completed by that stone, so the 64 lanes look at the cells of the four lines through
+// `last` instead of the scalar unit shifting whole bitboards (~400 SALU instructions per select, r4): 16 lanes per direction, lane
+// j of a group takes the cell j - (goal - 1) steps along it, a ballot packs the mover's stones into four 16-bit windows (bits
+// 2*goal-1.. of a window stay 0) and `goal` of them in a row is w & w>>1 & ... & w>>(goal-1) != 0 on the 64-bit mask (a window's
+// upper zeros stop runs from crossing into the next).  Only the mover can own a line (value -1 for the side to move); a full board
+// without one is a draw: the same (terminal, value) as terminal_test<KW, true> — utils.py:199-235 on such positions.  goal <= 8.
+template <int KW>
+__device__ __forceinline__ int terminal_through_last(const EngineParams& P, const u64* mine, const u64* theirs, int last, uint32_t inv_s16,
+                                                     int lane, float* value) {
+    const int S = P.S, g1 = P.goal - 1;
+    const int y0 = (int)(((uint32_t)last * inv_s16) >> 16), x0 = last - y0 * S;        // (exact for last < 256, S <= 16)
+    const int dir = lane >> 4, j = (lane & 15) - g1;
+    const int dy = dir == 1 ? 0 : (dir == 3 ? -1 : 1), dx = dir == 0 ? 0 : 1;         // down | right | down-right | up-right
+    const int y = y0 + j * dy, x = x0 + j * dx;
+    const bool inb = (lane & 15) <= 2 * g1 && (unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S;
+    const int c = inb ? y * S + x : 0;
+    u64 word = theirs[0];
+#pragma unroll
+    for (int k = 1; k < KW; ++k) word = (c >> 6) == k ? theirs[k] : word;
+    const u64 w = __ballot(inb && ((word >> (c & 63)) & 1ull));
+    u64 r = w;
+    for (int t = 1; t <= g1; ++t) r &= w >> t;
+    if (r) { *value = -1.0f; return 1; }
     bool full = true;
 #pragma unroll
     for (int k = 0; k < KW; ++k) full = full && ((mine[k] | theirs[k]) == P.boardmask[k]);
@@ -395,6 +444,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     uint32_t sel = rfl32(P.sel[g]);
     uint32_t plyctr = rfl32(P.plyctr[g]);
     const int random_a = rfli(P.random_a[g]);
+    const uint32_t inv_s16 = (65536u + (uint32_t)P.S - 1u) / (uint32_t)P.S;          // n / S = (n * inv_s16) >> 16 for n < 256
     const uint32_t k0 = P.k0, k1 = P.seed_hi + (P.first_game_id + (uint32_t)g);
     uint32_t ct[CT_N];   // this launch's share of the per-game counters
 #pragma unroll
@@ -753,7 +803,9 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         for (;;) {
             TK_T(tk_a);
             float tv;
-            if (terminal_test<KW, true>(P, cm, ctb, &tv)) {                 // :213-217
+            // (the root of a simulation keeps the whole-board scan: an EXTERNAL-mode caller may hand over any position with no last move)
+            if ((AF_TICK_TERM_LAST && depth > 0 && P.goal <= 8) ? terminal_through_last<KW>(P, cm, ctb, last, inv_s16, lane, &tv)
+                                                                : terminal_test<KW, true>(P, cm, ctb, &tv)) {                 // :213-217
                 backup(depth, tv, 0);
                 ct[CT_TERMINALS]++; ct[CT_SIMS]++;
                 sims_left--;
@@ -980,7 +1032,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                     for (int k = 0; k < KW; ++k) cand[k] = __ballot(((legal[k] >> lane) & 1ull) && nn[k] == 1);
                     m = bb_count<KW>(cand);
                 }
-                if (m > 0) cell = bb_select<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1));
+                if (m > 0) cell = bb_select_wave<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1), lane);
             }
             if (cell < 0) {                                                 // :277-279 argmax with uniform tie-break
                 mx = wave_max_f32(mx);
@@ -988,7 +1040,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
 #pragma unroll
                 for (int k = 0; k < KW; ++k) cand[k] = __ballot(((legal[k] >> lane) & 1ull) && sc[k] == mx);
                 const int m = bb_count<KW>(cand);
-                cell = bb_select<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1));
+                cell = bb_select_wave<KW>(cand, (int)af_pick((uint32_t)m, sel_id, episode, AF_STREAM_PICK, k0, k1), lane);
             }
             cell = rfli(cell);
             hint = 0;

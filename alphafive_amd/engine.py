@@ -357,6 +357,7 @@ class SelfPlayEngine:
         self._boxes = {}
         self._graph = None
         self._prog_host, self._prog_events, self._prog_turn, self._prog_replays = None, None, 0, 0
+        self.replay_events = []                      # (ticks, start event, end event) of the replays run with timed=True
 
     def tick(self):
         """One simulation step for every game: tree kernel -> leaf batch -> net."""
@@ -381,13 +382,14 @@ class SelfPlayEngine:
         ver = getattr(self.pv_device, "weights_version", None)
         return (int(n), self.engine.params_key(), ver() if callable(ver) else None)
 
-    def run_ticks_graph(self, n=16):
+    def run_ticks_graph(self, n=16, timed=False):
         """n ticks replayed as ONE HIP graph on the current stream (the tick kernel, the forward's 13 launches with the value
         branch's fork / join, and at the end a 16-byte copy of the engine's progress words into pinned host memory).  Returns at
         once; progress_lagged() reads the words one replay later, so polling never drains the device.  The graph is keyed on
         everything a launch has baked in: n, the engine's by-value parameters (training flag, simulation budget, per-launch select
         budget) and the evaluator's weight version — a change drops it, one eager tick re-packs the weights and the batch is
-        captured again (same protocol as Player._search_batch).  A failing capture raises: there is no silent eager fallback."""
+        captured again (same protocol as Player._search_batch).  A failing capture raises: there is no silent eager fallback.
+        timed=True brackets the replay with HIP timing events on its stream and appends them to self.replay_events."""
         torch = self.torch
         key = self._graph_key(n)
         if self._graph is None or self._graph[0] != key:
@@ -405,7 +407,13 @@ class SelfPlayEngine:
                 self.engine.progress_async(self._prog_host.data_ptr(), st)
             self.ticks -= n                          # (capture recorded the launches, it did not run them)
             self._graph = (self._graph_key(n), g)
+        if timed:                                    # HIP events around the replay, on the stream it runs on (bench.py reads them)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.dev))
         self._graph[1].replay()
+        if timed:
+            e1.record(torch.cuda.current_stream(self.dev))
+            self.replay_events.append((n, e0, e1))
         self.ticks += n
         self._prog_turn ^= 1
         self._prog_events[self._prog_turn].record(torch.cuda.current_stream(self.dev))

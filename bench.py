@@ -439,7 +439,7 @@ def main():
         sample = use_graph and timing["on"]
         while True:
             if use_graph:
-                sp.run_ticks_graph(args.poll)         # returns at once
+                sp.run_ticks_graph(args.poll, timed=timing["on"])         # returns at once
                 if sample:
                     # the sample that times the two kernels: eager launches bracketed by HIP events on the launch stream, inside
                     # the timed region, issued while the replay above keeps the device busy (no launch latency inside the
@@ -549,6 +549,16 @@ def main():
         n_ticks = ticks_timed                       # every tick of the timed region (graph replays + the event-timed sample)
         tick_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_tick]))
         net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net]))
+        net_ms_eager = net_ms
+        graph_tick_ms = None
+        if use_graph and sp.replay_events:
+            # what the timed region actually runs: the replays, each bracketed by HIP events on its stream.  One tick of a replay =
+            # af_tick_kernel + the forward; the tick kernel alone is a single launch whose eager, event-timed samples are what it
+            # takes inside the graph too, so the forward inside the graph = replay time per tick - tick kernel.  (The eager samples
+            # of the FORWARD carry the cost of its fork / join with the value branch's side stream as stream operations — a box-
+            # dependent 0-60 us that a graph edge does not have — and are kept as roofline.ms_per_launch_eager_sample.)
+            graph_tick_ms = float(np.sum([a.elapsed_time(b) for _, a, b in sp.replay_events]) / np.sum([n_ for n_, _, _ in sp.replay_events]))
+            net_ms = graph_tick_ms - tick_ms
         flop_pos = FLOP_PER_POSITION if cfg.board_size == 11 else net.flops_per_position()
         roof = net.roofline_info(pv)
         peak, dtype_name = roof.get("peak_tflops", PEAK_FP32_MFMA_TFLOPS), "f32"
@@ -561,9 +571,9 @@ def main():
         traffic_net = traffic_tick = None
         traffic_src = None
         pmc = None
-        tp = os.path.join(REPO, "profiles", "r3_pmc_hbm_traffic.json")
+        tp = os.path.join(REPO, "profiles", "r4_pmc_hbm_traffic.json")
         if not os.path.exists(tp):
-            tp = os.path.join(REPO, "profiles", "r2_pmc_hbm_traffic.json")
+            tp = os.path.join(REPO, "profiles", "r3_pmc_hbm_traffic.json")
         tp_name = "profiles/" + os.path.basename(tp)
         if os.path.exists(tp) and deep is None and roof["backend"].startswith("hip"):
             with open(tp) as f:
@@ -620,6 +630,10 @@ def main():
             "roofline": {"kernel": roof["kernel"], "bound": "mfma", "achieved": net_tflops,
                          "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "traffic": traffic_net, "traffic_source": traffic_src, "ms_per_launch": net_ms,
+                         "ms_per_launch_eager_sample": net_ms_eager,
+                         "ms_per_launch_source": ("HIP events around every graph replay of the timed region / ticks per replay - the tick kernel's "
+                                                  "event-timed launch duration (the forward as it runs inside the graph)") if graph_tick_ms else
+                                                 "HIP events around every eager forward of the timed region",
                          "flop_per_launch": G * flop_pos,
                          "note": "achieved = algorithmic (direct-convolution) FLOPs per launch / launch time; peak = dense MFMA peak of the "
                                  "operand type the kernel issues (fp16: 2.5 PFLOP/s; fp32: 157.3 TFLOP/s)"},
@@ -631,6 +645,7 @@ def main():
             "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms,
                            # what a tick costs beyond its two kernels: launch gaps, host polls, the hand-off (<= 5 us)
                            "outside_kernels_us_per_tick": 1e3 * (1e3 * t / max(1, n_ticks) - tick_ms - net_ms),
+                           "graph_replay_ms_per_tick": graph_tick_ms, "net_ms_per_tick_eager_sample": net_ms_eager,
                            "tree_ms_max": float(np.max([a.elapsed_time(b) for a, b in ev_tick])),
                            "tree_ms_p50": float(np.median([a.elapsed_time(b) for a, b in ev_tick]))},
             "tick_shape": {"selects_per_game_and_launch_hist": hist["selects"].tolist(),

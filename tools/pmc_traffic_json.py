@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""gpurun_out/pmc_traffic_r3.txt (tools/pmc_traffic_r3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC hit+miss in separate
-passes) -> profiles/r3_pmc_hbm_traffic.json, the file bench.py's roofline.traffic is read from.
+"""gpurun_out/pmc_traffic_r4.txt (tools/pmc_traffic_r4.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC hit+miss in separate
+passes) -> profiles/r4_pmc_hbm_traffic.json, the file bench.py's roofline.traffic is read from.
 usage: python tools/pmc_traffic_json.py [in.txt] [out.json]"""
 import json
 import os
@@ -8,8 +8,8 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "pmc_traffic_r3.txt")
-dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "r3_pmc_hbm_traffic.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "pmc_traffic_r4.txt")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "profiles", "r4_pmc_hbm_traffic.json")
 
 
 def short(name):
@@ -66,7 +66,7 @@ for k, c in kern.items():
 t = out[tick]
 doc = {
     "source": "rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc TCC_HIT_sum TCC_MISS_sum (three separate passes, --kernel-trace only; "
-              "tools/pmc_traffic_r3.sh) over tools/probe_tick_min.py: config 2 (4096 games, 11x11); counter unit KB per dispatch, mean over "
+              "tools/pmc_traffic_r4.sh) over tools/probe_tick_min.py: config 2 (4096 games, 11x11); counter unit KB per dispatch, mean over "
               "the last 400 dispatches of each kernel; assembled by tools/pmc_traffic_json.py. Passes: " + "; ".join(passes),
     "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read "
                   "(16 B/lane, global_load and LDS-DMA alike) -> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; WRITE_SIZE and mixed-width "
