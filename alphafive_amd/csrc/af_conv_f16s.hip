@@ -209,6 +209,9 @@ __device__ __forceinline__ f32x2 elu2(f32x2 x) {
 }
 #endif
 
+#ifndef AF_F16S_XCD_SWIZZLE
+#define AF_F16S_XCD_SWIZZLE 1
+#endif
 #ifdef AF_F16S_TIMING
 // profiling build only (tools/probe_f16s_timing.py): cycles per phase, [layer][workgroup (x + 256 y)][wave][phase]
 // phase 0 items (MFMA + reads + DMA issue), 1 vmcnt waits, 2 slab barriers, 3 k-split exchange (7: its barrier alone), 4 epilogue,
@@ -284,7 +287,13 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     // pseudo-position q = HALVES * position + half; this workgroup takes q0, q0 + gridDim.x, ... (gridDim.x is a multiple of
     // HALVES, so the half — and with it every lane's pixel, window and edge flags — is fixed for the whole launch)
     const int nq = A.batch * HV;
+    // Which pseudo-positions a workgroup takes (r4): consecutive workgroup ids land on consecutive XCDs, so with q0 = blockIdx.x the 32
+    // workgroups of XCD k would walk the positions = k (mod 8) only — one residue class of the activation addresses per XCD, all in
+    // step — and the XCDs finish 3 % apart, launch after launch, even ones late (profiles/r4_03).  With the swizzle XCD k takes the
+    // CONTIGUOUS positions 32k .. 32k+31 (+ gridDim.x per pass): every XCD touches every address residue.  A position's result does
+    // not depend on which workgroup computes it (same bits); gridDim.x / 8 is a multiple of HALVES whenever the swizzle is used.
     int qpos = blockIdx.x;
+    if (AF_F16S_XCD_SWIZZLE && (gridDim.x & (8 * HV - 1)) == 0) qpos = (int)(blockIdx.x >> 3) + (int)(gridDim.x >> 3) * (int)(blockIdx.x & 7);
     if (qpos >= nq) return;
     const int hv = HV == 1 ? 0 : qpos % HV;
     const uint32_t wsrc = G::wbase(hv) * 16u;          // byte offset of the half's window inside a unit row (HBM)
