@@ -982,6 +982,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // positions' inputs are staged through LDS 16 pixels at a time per K half (transposed to [half][pixel][channel octet][position]
 // rows of 528 bytes: conflict-free ds_read_b128 B fragments), the A fragments ride a register ring of 16 / MT steps.
 constexpr uint32_t kPfRow = 528u, kPfBuf = 64u * kPfRow;
+#ifndef AF_PFC_POS
+#define AF_PFC_POS 32
+#endif
+// positions per workgroup of af_policy_fc_f16s (A/B knob, r4_26): 32 = 128 workgroups 31.3 us, 16 = 256 workgroups 31.6 us, 8 = 512
+// workgroups 54 us per 4096 positions — twice the workgroups stream twice the dense weights out of L2 in the same time: the kernel
+// is bound by that stream, not by the number of CUs it runs on
+constexpr int kPfPos = AF_PFC_POS;
 constexpr uint32_t kPfLds = 4u * kPfBuf;                                    // [K half][double buffer]; later the logits [32][32 NLT] floats
 template <class G>
 __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restrict__ xp, const uint4* __restrict__ a /*[S*S][NLT][hi|lo][64]*/,
@@ -993,7 +1000,8 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
     // were exec-masked regions whose ring refills hipcc waited for on the spot (vmcnt(0) after every refill: r3_47)
     const int t = threadIdx.x & 255, lane = t & 63, n = lane & 31, kg = lane >> 5;
     const int kh = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), mt = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int b0 = (int)blockIdx.x * 32;
+    // (a workgroup's MFMA columns are 32 position slots; with kPfPos < 32 slot n holds position n mod kPfPos: see kPfPos)
+    const int b0 = (int)blockIdx.x * kPfPos;
     char* const sm = psm + (uint32_t)kh * 2u * kPfBuf;
     // K half kh = chunks NCH kh .. NCH kh + NCH - 1 of 16 pixels (the last ones are partly / wholly past S*S).  Staging of a
     // chunk: unit u = 256 i + t, i = 0..7: segment u >> 5 = (position, half), 16-byte unit u & 31 = (pixel, octet)
@@ -1002,7 +1010,8 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int u = 256 * i + t, seg = u >> 5, pl = seg >> 1, hl = seg & 1, wi = u & 31, px = wi >> 1, oc = wi & 1;
-        const int p = b0 + pl < batch ? b0 + pl : batch - 1;
+        const int pq = b0 + (pl & (kPfPos - 1));
+        const int p = pq < batch ? pq : batch - 1;
         src[i] = xp + (size_t)p * Hx<G>::kPolPos + (uint32_t)hl * Hx<G>::kPolLo + (uint32_t)((HXP / 2) * kh + px) * 32u + (uint32_t)oc * 16u;
         dst[i] = (uint32_t)((hl * 16 + px) * 2 + oc) * kPfRow + (uint32_t)pl * 16u;
     }
@@ -1094,7 +1103,7 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
     for (int q = 0; q < NV; ++q) { v[q] = (sub + 16 * q) < NPIX ? expf(v[q] - mx) : 0.0f; sum += v[q]; }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-    if (b0 + p < batch) {
+    if (p < kPfPos && b0 + p < batch) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int j = sub + 16 * q;
@@ -1481,10 +1490,10 @@ int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP
     if (!rc) rc = launch_layer(n, st, 9, n->g[4], n->o[3], nullptr, o5, batch, WP, PP, policy ? 1 : -1);
     if (!rc && policy) {
         if (n->S == 11)
-            hipLaunchKernelGGL(af_policy_fc_f16s<Geo<11>>, dim3((batch + 31) / 32), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
+            hipLaunchKernelGGL(af_policy_fc_f16s<Geo<11>>, dim3((batch + kPfPos - 1) / kPfPos), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
                                n->hf_inv[1], policy, batch);
         else
-            hipLaunchKernelGGL(af_policy_fc_f16s<Geo<15>>, dim3((batch + 31) / 32), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
+            hipLaunchKernelGGL(af_policy_fc_f16s<Geo<15>>, dim3((batch + kPfPos - 1) / kPfPos), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
                                n->hf_inv[1], policy, batch);
     }
     return rc;

@@ -86,6 +86,17 @@ __device__ __forceinline__ f32x2 elu2(f32x2 x) {
     return f32x2{fmaxf(x.x, em1.x), fmaxf(x.y, em1.y)};
 }
 
+// First position of a persistent workgroup (r4, as in af_conv_f16s.hip): consecutive workgroup ids sit on consecutive XCDs, so with
+// pos = blockIdx.x the 32 workgroups of XCD k would walk the positions = k (mod 8) only; XCD k takes the contiguous positions
+// 32k..32k+31 (+ gridDim.x per pass) instead.  A position's result does not depend on the workgroup that computes it.
+#ifndef AF_TOWER_XCD_SWIZZLE
+#define AF_TOWER_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ int first_position() {
+    if (AF_TOWER_XCD_SWIZZLE && (gridDim.x & 7) == 0) return (int)(blockIdx.x >> 3) + (int)(gridDim.x >> 3) * (int)(blockIdx.x & 7);
+    return (int)blockIdx.x;
+}
+
 struct TowerArgs {
     const char* in;      // C8 bf16 [batch][16][PIX][8]: input of the 3x3 convolution
     const char* in2;     // PROJ: block input (1x1 projection), same layout
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) stage_round(src, pos, off, r);
     };
-    int pos = blockIdx.x;
+    int pos = first_position();
     if (pos >= A.batch) return;
     constexpr uint32_t kZoff = kLds0 + (PROJ ? 3u : 2u) * kPlaneB;      // the zero region follows the planes
     for (uint32_t u = threadIdx.x; u < kZeroB / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv3(TowerArgs A) {
         glds16(src + (size_t)pos * kPlaneB + threadIdx.x * 16u + r * 4096,
                (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + off + wv * 1024u + r * 4096u)));
     };
-    int pos = blockIdx.x;
+    int pos = first_position();
     if (pos >= A.batch) return;
     constexpr uint32_t kZoff = kLds0 + (PROJ ? 3u : 2u) * kPlaneB;      // the zero region follows the planes
     for (uint32_t u = threadIdx.x; u < kZeroB / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};

@@ -107,8 +107,8 @@ class EpisodeGather(object):
     collect() must come before the next pack: the gather it issues reads the previously posted buffer (the collective is
     ordered with the current stream, so the pack that follows cannot overtake it).
     Rank 0's share of a step is O(world) small calls and no per-episode work: sizes (one event that retired a step ago),
-    one gather into a receive buffer that is allocated once, one strided device-to-pinned copy into a ring of pinned
-    buffers that is allocated once, and — with unpack=False — PackedEpisodes views whose headers carry the counts
+    one gather into a receive buffer that is allocated once, `world` asynchronous device-to-pinned copies of the used row prefixes
+    into a ring of pinned buffers that is allocated once, and — with unpack=False — PackedEpisodes views whose headers carry the counts
     (bench.py reads n / plies only; a trainer unpacks where it needs the records, see PackedEpisodes).  unpack=True
     (default, tests and one-off callers) returns raw episode dicts as before.
     max_eps / rec_ints describe the pack layout (af_engine_pack_episodes: used = 4 + 5*max_eps + plies*rec_ints).
@@ -207,7 +207,8 @@ class EpisodeGather(object):
         self.bytes_received += sum(sizes[1:]) * 4
         ev = None
         if recv.device.type == "cuda":
-            host[:, :width].copy_(recv[:, :width], non_blocking=True)          # ONE strided copy: rows of `width` ints
+            for r in range(self.world):               # contiguous row prefixes: plain asynchronous device-to-pinned copies (a strided
+                host[r, :sizes[r]].copy_(recv[r, :sizes[r]], non_blocking=True)      # 2-D copy_ would stage through a temporary)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(recv.device))
         t["host"], t["ev"] = host, ev
