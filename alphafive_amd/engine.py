@@ -400,7 +400,9 @@ class SelfPlayEngine:
             self.tick()                              # outside the capture: weight reload, lazy allocations, side-stream creation
             torch.cuda.synchronize(self.dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: only THIS thread's calls can invalidate the capture — a process that also runs RCCL has a watchdog
+            # thread querying events while we capture (multi-GPU bench: the process group is up before the first graph)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 for _ in range(n):
                     self.tick()
                 st = torch.cuda.current_stream(self.dev).cuda_stream

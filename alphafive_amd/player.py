@@ -227,7 +227,7 @@ class Player(object):
             self._evaluate_leaf()                    # warm-up outside the capture (weight reload, lazy allocations)
             torch.cuda.synchronize(self._dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # (other threads — an RCCL watchdog — may touch the runtime)
                 st = torch.cuda.current_stream(self._dev).cuda_stream
                 for _ in range(n):
                     self._engine.tick(self._policy.data_ptr(), self._value.data_ptr(), self._planes.data_ptr(), st)

@@ -47,9 +47,13 @@ def main():
     gat = afdist.EpisodeGather(1, 0, dev, cap, 2 * a.engine.KW2 + 2 * 36 + 2, games_per_rank=G)
     assert gat.collective
     got, ref = [], []
-    for _ in range(10):
+    for it in range(10):
         for sp in (a, b):
-            sp.run_ticks(300)
+            if sp is a and it >= 2:             # the HIP-graph loop with the RCCL process group (and its watchdog thread) alive:
+                for _ in range(15):             # bench.py's N > 1 situation — capture and replays must work next to the collectives
+                    sp.run_ticks_graph(20)
+            else:
+                sp.run_ticks(301 if (sp is b and it == 2) else 300)      # (a's first replay is preceded by one eager warm-up tick)
             sp.check()
         got += gat.collect()
         gat.post(a.post_episodes_device(cap))
