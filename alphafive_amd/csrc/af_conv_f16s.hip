@@ -990,17 +990,29 @@ constexpr uint32_t kPfRow = 528u, kPfBuf = 64u * kPfRow;
 // is bound by that stream, not by the number of CUs it runs on
 constexpr int kPfPos = AF_PFC_POS;
 constexpr uint32_t kPfLds = 4u * kPfBuf;                                    // [K half][double buffer]; later the logits [32][32 NLT] floats
+#ifdef AF_PFC_TIMING
+// profiling build only (tools/probe_pfc_timing.py): per wave, device-wide 100 MHz clock at entry | operands of the first chunk in place |
+// K loop done | K halves combined | softmax + stores done
+__device__ unsigned long long g_pfc_wall[256][8][5];
+#define PF_T(i) if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_pfc_wall[blockIdx.x][threadIdx.x >> 6][i] = wall_clock64()
+#else
+#define PF_T(i)
+#endif
 template <class G>
 __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restrict__ xp, const uint4* __restrict__ a /*[S*S][NLT][hi|lo][64]*/,
                                                             const float* __restrict__ bf, float inv_scale, float* __restrict__ policy, int batch) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     constexpr int NPIX = G::NPIX, HXP = Hx<G>::HXP, NLT = Hx<G>::NLT, MT = NLT / 4, RD = 16 / MT, NCH = HXP / 32, LW = 32 * NLT;
-    static_assert(NLT % 4 == 0 && LW * 32 * 4 <= (int)kPfLds, "logit tiles");
+    // a position's logits in LDS are LWP = LW + 1 floats apart: with LW (a multiple of 32 banks) the 32 position lanes of a store
+    // hit ONE bank — 32-way conflicts through the whole combine phase (5.3 of the kernel's 32 us, profiles/r4_27)
+    constexpr int LWP = LW + 1;
+    static_assert(NLT % 4 == 0 && LWP * 32 * 4 <= (int)kPfLds, "logit tiles");
     // kh and mt are wave-uniform: as scalars (readfirstlane) the step bounds below are scalar branches; as functions of threadIdx they
     // were exec-masked regions whose ring refills hipcc waited for on the spot (vmcnt(0) after every refill: r3_47)
     const int t = threadIdx.x & 255, lane = t & 63, n = lane & 31, kg = lane >> 5;
     const int kh = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), mt = __builtin_amdgcn_readfirstlane(t >> 6);
     // (a workgroup's MFMA columns are 32 position slots; with kPfPos < 32 slot n holds position n mod kPfPos: see kPfPos)
+    PF_T(0);
     const int b0 = (int)blockIdx.x * kPfPos;
     char* const sm = psm + (uint32_t)kh * 2u * kPfBuf;
     // K half kh = chunks NCH kh .. NCH kh + NCH - 1 of 16 pixels (the last ones are partly / wholly past S*S).  Staging of a
@@ -1036,6 +1048,7 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     __syncthreads();
+    PF_T(1);
     for (int c = 0; c < NCH; ++c) {
         const uint32_t cur = (uint32_t)(c & 1) * kPfBuf, nxt = kPfBuf - cur;
         if (c < NCH - 1) {
@@ -1072,13 +1085,14 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
         }
         __syncthreads();
     }
+    PF_T(2);
     // the two K halves meet in LDS (the staging buffers are dead): rows of a lane = logits 32 (mt + 4 m) + 16 kg + r
-    float* Lg = reinterpret_cast<float*>(psm);                               // [32 positions][LW]
+    float* Lg = reinterpret_cast<float*>(psm);                               // [32 positions][LWP]
     if (kh == 1) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Lg[n * LW + 32 * (mt + 4 * m) + 16 * kg + r] = acc[m][r];
+            for (int r = 0; r < 16; ++r) Lg[n * LWP + 32 * (mt + 4 * m) + 16 * kg + r] = acc[m][r];
     }
     __syncthreads();
     if (kh == 0) {
@@ -1087,15 +1101,16 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = 32 * (mt + 4 * m) + 16 * kg + r;
-                Lg[n * LW + j] = j < NPIX ? (acc[m][r] + Lg[n * LW + j]) * inv_scale + bf[j] : -3.0e38f;
+                Lg[n * LWP + j] = j < NPIX ? (acc[m][r] + Lg[n * LWP + j]) * inv_scale + bf[j] : -3.0e38f;
             }
     }
     __syncthreads();
+    PF_T(3);
     const int p = (int)threadIdx.x >> 4, sub = (int)threadIdx.x & 15;        // 16 threads per position, LW / 16 logits each
     constexpr int NV = LW / 16;
     float v[NV], mx = -3.0e38f;
 #pragma unroll
-    for (int q = 0; q < NV; ++q) { v[q] = Lg[p * LW + sub + 16 * q]; mx = fmaxf(mx, v[q]); }
+    for (int q = 0; q < NV; ++q) { v[q] = Lg[p * LWP + sub + 16 * q]; mx = fmaxf(mx, v[q]); }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     float sum = 0.0f;
@@ -1110,7 +1125,15 @@ __global__ __launch_bounds__(512, 1) void af_policy_fc_f16s(const char* __restri
             if (j < NPIX) policy[(size_t)(b0 + p) * NPIX + j] = v[q] / sum;
         }
     }
+    PF_T(4);
 }
+#ifdef AF_PFC_TIMING
+extern "C" int af_pfc_debug_wall(unsigned long long* host) {
+    FS_HIP_OK(hipDeviceSynchronize());
+    FS_HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pfc_wall), sizeof(unsigned long long) * 256 * 8 * 5));
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------ host ------------------------------------------------------------------
 struct LayerCfg { int cin, cout, pcin, CT, KS, PS, gy, pj; };
