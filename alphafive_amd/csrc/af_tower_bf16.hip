@@ -816,6 +816,66 @@ __global__ __launch_bounds__(256) void af_tower_heads_kernel(HeadsArgs A) {
     }
 }
 
+// af_tower_heads_mfma_kernel (r4): the same 1x1 convolutions on the matrix cores.  The VALU kernel above re-reads its 20 x 128 weights
+// from LDS for every pixel (320 16-byte LDS reads per thread) and takes 198 us per 8192 positions against a 75-us HBM bound.  Here a
+// wave = one 32-pixel tile of a position: M = 32 output rows (4 value + 16 policy channels, the rest zero weights), K = 128 channels =
+// 8 k-steps whose B fragment is exactly one 16-byte C8 unit per lane (8 channels of the lane's pixel: straight from global memory,
+// 512 contiguous bytes per half wave), A fragments (8 x 16 bytes per lane) resident.  The weight rows are permuted at pack time like
+// the tower's, so a lane holds outputs 16 kg + r: bias, ELU, bf16, 2-byte stores that are contiguous over the 32 pixels of a tile.
+struct HeadsMfmaArgs {
+    const char* x;       // C8 bf16
+    const uint4* a;      // [8 k-steps][64 lanes] A fragments (8 bf16)
+    const float* b;      // [32]: bias of output o (0 for o >= 20)
+    __bf16* vin;         // [B][484]
+    __bf16* pin;         // [B][1936]
+    int batch;
+};
+
+__global__ __launch_bounds__(256) void af_tower_heads_mfma_kernel(HeadsMfmaArgs A) {
+    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
+    const int j = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // pixel tile
+    const int p = 32 * j + nn, pc = p < kNPIX ? p : 0;
+    bf16x8 W[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { const uint4 v = A.a[s * 64 + lane]; __builtin_memcpy(&W[s], &v, 16); }
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = A.b[16 * kg + r];
+    const uint32_t off = (uint32_t)(kg * kPIX + pc + kS) * 16u;                   // the lane's unit inside channel-group plane kg
+    uint4 cur[8], nxt[8];
+    int pos = blockIdx.x;
+    if (pos >= A.batch) return;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) cur[s] = *reinterpret_cast<const uint4*>(A.x + (size_t)pos * kPlaneB + off + (uint32_t)(2 * s * kPIX) * 16u);
+    for (; pos < A.batch; pos += gridDim.x) {
+        const int np = pos + (int)gridDim.x < A.batch ? pos + (int)gridDim.x : pos;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) nxt[s] = *reinterpret_cast<const uint4*>(A.x + (size_t)np * kPlaneB + off + (uint32_t)(2 * s * kPIX) * 16u);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            bf16x8 y;
+            __builtin_memcpy(&y, &cur[s], 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s], y, acc, 0, 0, 0);
+        }
+        if (p < kNPIX) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 16 * kg + r;                                            // (kg = 1: only o = 16..19 exist)
+                if (o < 20) {
+                    const __bf16 yv = (__bf16)elu1(acc[r] + bias_r[r]);
+                    if (o < 4) A.vin[(size_t)pos * (4 * kNPIX) + o * kNPIX + p] = yv;
+                    else A.pin[(size_t)pos * (16 * kNPIX) + (o - 4) * kNPIX + p] = yv;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) cur[s] = nxt[s];
+    }
+}
+
 // af_tower_dense_kernel: the three dense layers and the softmax behind the heads' 1x1 convolutions (network.py:73-76,85-88)
 // for 32 positions per workgroup on the same MFMA: D[out][position] = sum_k W^T[out][k] * in[position][k].
 //   policy: 1936 -> 121 (+ bias) -> softmax: wave w owns outputs 32w..32w+31 (121 padded to 128 with zero weights), 121 k-steps
@@ -936,6 +996,8 @@ struct af_tower {
     float* stem_b = nullptr;
     float* heads_w = nullptr;
     float* heads_b = nullptr;
+    uint4* heads_a = nullptr;     // af_tower_heads_mfma_kernel: A fragments
+    float* heads_b32 = nullptr;   // ... and its 32 biases
     uint4 *dense_wp = nullptr, *dense_wv = nullptr;     // af_tower_dense_kernel: packed policy / value fc1 weights
     float *dense_pb = nullptr, *dense_vb1 = nullptr, *dense_vw2 = nullptr;
     float dense_vb2 = 0.0f;
@@ -1010,6 +1072,7 @@ static int upload(T** dst, const void* src, size_t bytes) {
 static int g_depth = 0;     // B-fragment ring depth (A/B knob; 0 = per-kernel default)
 static int g_abl = 0;       // profiling ablations (results wrong by design)
 static int g_grid = 0;      // persistent workgroups (0 = one per CU)
+static int g_heads = 1;     // heads' 1x1 convolutions: 1 = af_tower_heads_mfma_kernel (r4), 0 = the VALU kernel (A/B)
 static int g_engine = 3;    // 3 (default, r4): af_tower_conv3 for a block's first convolution + af_tower_conv for its second (bit-identical to 0,
                             //    4.143 vs 4.167 ms per 8192-position tower pass); 0: af_tower_conv for both; 2: af_tower_conv3 for both (its
                             //    PROJ form is slower: 4.224 ms); 1: af_tower_conv2 (r2 experiment: 5.37 ms — its 32-channel slabs give a
@@ -1022,6 +1085,7 @@ int af_tower_tune(int32_t key, int32_t value) {
     if (key == 1) { g_grid = value; return AF_TOWER_OK; }
     if (key == 2) { g_abl = value; return AF_TOWER_OK; }
     if (key == 3) { g_engine = value; return AF_TOWER_OK; }
+    if (key == 4) { g_heads = value; return AF_TOWER_OK; }
     return AF_TOWER_ERR_ARG;
 }
 
@@ -1069,6 +1133,8 @@ void af_tower_destroy(af_tower* t) {
     if (t->stem_b) (void)hipFree(t->stem_b);
     if (t->heads_w) (void)hipFree(t->heads_w);
     if (t->heads_b) (void)hipFree(t->heads_b);
+    if (t->heads_a) (void)hipFree(t->heads_a);
+    if (t->heads_b32) (void)hipFree(t->heads_b32);
     if (t->dense_wp) (void)hipFree(t->dense_wp);
     if (t->dense_wv) (void)hipFree(t->dense_wv);
     if (t->dense_pb) (void)hipFree(t->dense_pb);
@@ -1124,6 +1190,20 @@ int af_tower_set_heads(af_tower* t, const float* vconv_w, const float* vconv_b, 
     }
     int rc = upload(&t->heads_w, w.data(), w.size() * 4);
     if (!rc) rc = upload(&t->heads_b, b.data(), b.size() * 4);
+    // A fragments of the MFMA kernel: [k-step][lane][e] = W[o = perm(lane & 31)][ch = 16 step + 8 (lane >> 5) + e] (same row permutation
+    // as pack_tower: a lane's accumulator rows are 16 consecutive outputs)
+    auto perm = [](int m) { return 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3); };
+    std::vector<uint16_t> a((size_t)8 * 64 * 8, 0);
+    for (int step = 0; step < 8; ++step)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+                const int o = perm(lane & 31), ch = 16 * step + 8 * (lane >> 5) + e;
+                if (o < 20) a[((size_t)step * 64 + lane) * 8 + e] = bf16_rne(w[o * 128 + ch]);
+            }
+    std::vector<float> b32(32, 0.0f);
+    for (int o = 0; o < 20; ++o) b32[o] = b[o];
+    if (!rc) rc = upload(&t->heads_a, a.data(), a.size() * 2);
+    if (!rc) rc = upload(&t->heads_b32, b32.data(), b32.size() * 4);
     return rc;
 }
 
@@ -1192,7 +1272,13 @@ int af_tower_heads(af_tower* t, void* stream, const void* x_dev, void* vin_dev, 
     a.x = static_cast<const char*>(x_dev); a.w = t->heads_w; a.b = t->heads_b;
     a.vin = static_cast<__bf16*>(vin_dev); a.pin = static_cast<__bf16*>(pin_dev); a.batch = batch;
     const int grid = batch < 2048 ? batch : 2048;
-    hipLaunchKernelGGL(af_tower_heads_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (g_heads == 0) {
+        hipLaunchKernelGGL(af_tower_heads_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    } else {
+        HeadsMfmaArgs m;
+        m.x = a.x; m.a = t->heads_a; m.b = t->heads_b32; m.vin = a.vin; m.pin = a.pin; m.batch = batch;
+        hipLaunchKernelGGL(af_tower_heads_mfma_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), m);
+    }
     TW_HIP_OK(hipGetLastError());
     return AF_TOWER_OK;
 }
