@@ -908,13 +908,29 @@ __global__ __launch_bounds__(256) void af_tower_dense_kernel(DenseArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         const __bf16* prow = A.pin + (size_t)pos * 1936 + 8 * kg;
-        for (int k = 0; k < 121; ++k) {
-            const u32x4d a = *reinterpret_cast<const u32x4d*>(A.wp + ((size_t)k * 4 + wv) * 64 + lane);
-            const u32x4d b = *reinterpret_cast<const u32x4d*>(prow + 16 * k);
-            bf16x8 x, y;
-            __builtin_memcpy(&x, &a, 16);
-            __builtin_memcpy(&y, &b, 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+        // operands on a kRing-deep register ring (r4): rolled, hipcc pipelined the loop by ONE step (wait, MFMA, issue the next two loads),
+        // so each of the 121 steps paid an L2 / HBM round trip: 80 us per 8192 positions for ~6 us of MFMA work
+        constexpr int kRing = 8;
+        u32x4d ra[kRing], rb[kRing];
+#pragma unroll
+        for (int q = 0; q < kRing; ++q) {
+            ra[q] = *reinterpret_cast<const u32x4d*>(A.wp + ((size_t)q * 4 + wv) * 64 + lane);
+            rb[q] = *reinterpret_cast<const u32x4d*>(prow + 16 * q);
+        }
+        for (int k0 = 0; k0 < 121; k0 += kRing) {
+#pragma unroll
+            for (int q = 0; q < kRing; ++q) {
+                const int k = k0 + q;
+                if (k < 121) {
+                    bf16x8 x, y;
+                    __builtin_memcpy(&x, &ra[q], 16);
+                    __builtin_memcpy(&y, &rb[q], 16);
+                    const int kn = k + kRing < 121 ? k + kRing : 120;          // (past the end: the last step again, never used)
+                    ra[q] = *reinterpret_cast<const u32x4d*>(A.wp + ((size_t)kn * 4 + wv) * 64 + lane);
+                    rb[q] = *reinterpret_cast<const u32x4d*>(prow + 16 * kn);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+                }
+            }
         }
         // a lane holds the outputs 32*wv + 16*kg + r of position nn (rows permuted at pack time)
         float mx = -3.0e38f;
@@ -954,8 +970,7 @@ __global__ __launch_bounds__(256) void af_tower_dense_kernel(DenseArgs A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) av[r] = 0.0f;
             const __bf16* vrow = A.vin + (size_t)pos * 484 + 8 * kg;
-            for (int k = 0; k < 31; ++k) {
-                const u32x4d a = *reinterpret_cast<const u32x4d*>(A.wv + ((size_t)k * 2 + wv) * 64 + lane);
+            auto load_b = [&](int k) -> u32x4d {
                 u32x4d b = {0u, 0u, 0u, 0u};
                 if (16 * k + 8 * kg + 8 <= 484) b = *reinterpret_cast<const u32x4d*>(vrow + 16 * k);
                 else if (16 * k + 8 * kg < 484) {                          // the last, partial 8-group: 484 = 30*16 + 4
@@ -964,10 +979,28 @@ __global__ __launch_bounds__(256) void af_tower_dense_kernel(DenseArgs A) {
                     for (int e = 0; e < 8; ++e) t8[e] = 16 * k + 8 * kg + e < 484 ? vrow[16 * k + e] : (__bf16)0.0f;
                     __builtin_memcpy(&b, t8, 16);
                 }
-                bf16x8 x, y;
-                __builtin_memcpy(&x, &a, 16);
-                __builtin_memcpy(&y, &b, 16);
-                av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, av, 0, 0, 0);
+                return b;
+            };
+            u32x4d va[kRing], vb[kRing];                                   // the same register ring as the policy loop
+#pragma unroll
+            for (int q = 0; q < kRing; ++q) {
+                va[q] = *reinterpret_cast<const u32x4d*>(A.wv + ((size_t)q * 2 + wv) * 64 + lane);
+                vb[q] = load_b(q);
+            }
+            for (int k0 = 0; k0 < 31; k0 += kRing) {
+#pragma unroll
+                for (int q = 0; q < kRing; ++q) {
+                    const int k = k0 + q;
+                    if (k < 31) {
+                        bf16x8 x, y;
+                        __builtin_memcpy(&x, &va[q], 16);
+                        __builtin_memcpy(&y, &vb[q], 16);
+                        const int kn = k + kRing < 31 ? k + kRing : 30;
+                        va[q] = *reinterpret_cast<const u32x4d*>(A.wv + ((size_t)kn * 2 + wv) * 64 + lane);
+                        vb[q] = load_b(kn);
+                        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, av, 0, 0, 0);
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -382,6 +382,13 @@ def test_deep_bf16_tower_kernel_matches_fp32_reference(blocks):
     p_ref = F.elu(F.conv2d(h, net.pconv[0].float(), net.pconv[1].float())).reshape(B, -1)
     assert (vin.float() - v_ref).abs().max().item() <= 2.0 ** -8 * v_ref.abs().max().item() + 1e-6
     assert (pin.float() - p_ref).abs().max().item() <= 2.0 ** -8 * p_ref.abs().max().item() + 1e-6
+    try:                                             # (af_tower_tune key 4: 0 = the VALU heads kernel the MFMA one replaced in r4)
+        tower_hip.tune(4, 0)
+        vin0, pin0 = (t.clone() for t in tw.heads(B))
+    finally:
+        tower_hip.tune(4, 1)
+    assert (vin0.float() - v_ref).abs().max().item() <= 2.0 ** -8 * v_ref.abs().max().item() + 1e-6
+    assert (pin0.float() - p_ref).abs().max().item() <= 2.0 ** -8 * p_ref.abs().max().item() + 1e-6
     # the MFMA dense kernel (fc1+ELU, fc2+tanh(x/2), policy fc + softmax) vs the same layers on PyTorch ops: bf16 inputs and
     # weights on both sides; the kernel keeps fp32 between the layers where the torch path rounds to bf16
     net.vfc1 = (net.vfc1[0], (torch.randn(64, generator=g) * 0.1).to("cuda", torch.bfloat16))
