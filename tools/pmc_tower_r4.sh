@@ -31,7 +31,7 @@ for sec in t.split("## engine ")[1:]:
                 continue
             f = line.split()
             name = cur
-            ctr.setdefault(name, {})["avg_ns"] = float(f[-5])
+            ctr.setdefault(name, {})["avg_ns"] = float(f[-4])
         m = re.match(r"\s+(\S+)\s+n=\d+\s+mean=(\S+)", line)
         if m and cur:
             ctr[cur][m.group(1)] = float(m.group(2))
