@@ -38,6 +38,19 @@ def test_bench_line_carries_the_contract():
     # the dominant kernel cannot take longer than a step allows
     ticks = d["config"]["ticks_timed_rank0"] / d["steps"]
     assert ticks * (r["ms_per_launch"] + d["tree_roofline"]["ms_per_launch"]) < 1.03 * d["ms_per_step"]
+    # r4: the line carries what DESIGN argues about the power-bound chip — reproducible from the line alone
+    assert 1.5 < r["sustained_clock_ghz"] < 2.45 and r["nominal_clock_ghz"] == 2.4 and 0.3 < r["mfma_busy"] < 0.9
+    assert abs(r["sustained_peak_tflops"] - r["peak"] * r["sustained_clock_ghz"] / 2.4) < 1e-6 * r["peak"]
+    assert abs(r["frac_of_sustained_peak"] - r["achieved"] / r["sustained_peak_tflops"]) < 1e-9
+    assert abs(r["mfma_issued_frac_of_sustained_peak"] - r["mfma_issued_tflops"] / r["sustained_peak_tflops"]) < 1e-9
+    pk = r["per_kernel"]
+    assert len(pk) >= 12 and all(set(("kernel", "us", "ghz", "mfma_busy", "mfma_issued_tflops", "hbm_mb")) <= set(e) for e in pk)
+    assert abs(sum(e["us"] * e["launches_per_forward"] for e in pk) - r["profiled_forward_us"]) < 1e-6 * r["profiled_forward_us"]
+    assert abs(sum(e["hbm_mb"] * e["launches_per_forward"] for e in pk) * 1e6 - r["traffic"]) < 0.01 * r["traffic"]
+    # the forward as it runs inside the graph: replay time per tick - tick kernel; what lies outside the replays is small
+    ts = d["time_split"]
+    assert abs(ts["graph_replay_ms_per_tick"] - ts["tree_ms_per_tick"] - r["ms_per_launch"]) < 1e-9
+    assert abs(ts["outside_kernels_us_per_tick"]) < 10.0 and "HIP graph" in d["config"]["loop"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
