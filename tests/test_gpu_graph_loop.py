@@ -116,3 +116,27 @@ def test_graph_loop_with_the_hand_written_net_follows_budget_and_weight_changes(
         assert (ta["w"].view(np.uint32) == tb["w"].view(np.uint32)).all() and (ta["p"].view(np.uint32) == tb["p"].view(np.uint32)).all()
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("board,goal,value_f64", [(15, 5, False), (7, 4, True)])
+def test_graph_loop_on_the_other_instantiations(board, goal, value_f64):
+    """af_tick_kernel<4, false> (15x15: four-word bitboards) and <2, true> (fp64 W / Q: the pipe path's arithmetic) inside the graph:
+    same counters, progress and trees as the eager loop after the same number of ticks."""
+    from alphafive_amd.engine import SelfPlayEngine
+    cfg = make_cfg(board_size=board, goal=goal, simulation_per_step=50, upper_simulation_per_step=70)
+    G = 40
+    mk = lambda: SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, 11, 8192, vbits=24), device=0, seed=4, value_f64=value_f64)
+    a, b = mk(), mk()
+    for _ in range(30):
+        a.run_ticks_graph(12)
+    b.run_ticks(a.ticks)
+    a.check(), b.check()
+    assert a.counters() == b.counters() and a.progress() == b.progress() and a.counters()["plies"] > G
+    for g in (0, G - 1):
+        ta, tb = a.engine.tree_dump(g), b.engine.tree_dump(g)
+        for k in ("keys", "sum_n", "n"):
+            assert (ta[k] == tb[k]).all(), k
+        assert ta["w"].tobytes() == tb["w"].tobytes() and ta["p"].tobytes() == tb["p"].tobytes()
+    assert [(e["game"], e["seq"], e["T"]) for e in _drain(a)] == [(e["game"], e["seq"], e["T"]) for e in _drain(b)]
+    a.close()
+    b.close()
