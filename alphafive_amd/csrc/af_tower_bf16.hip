@@ -898,6 +898,8 @@ struct DenseArgs {
 
 __global__ __launch_bounds__(256) void af_tower_dense_kernel(DenseArgs A) {
     __shared__ float s_red[4][2][32];         // [wave][lane half][position]: partial max / sum / dot
+    constexpr int kStageBuf = 32 * 528;
+    __shared__ __attribute__((aligned(16))) char s_stage[2 * kStageBuf];      // policy rows of the 32 positions, 16 k-steps at a time
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     typedef uint32_t u32x4d __attribute__((ext_vector_type(4)));
@@ -907,30 +909,52 @@ __global__ __launch_bounds__(256) void af_tower_dense_kernel(DenseArgs A) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const __bf16* prow = A.pin + (size_t)pos * 1936 + 8 * kg;
-        // operands on a kRing-deep register ring (r4): rolled, hipcc pipelined the loop by ONE step (wait, MFMA, issue the next two loads),
-        // so each of the 121 steps paid an L2 / HBM round trip: 80 us per 8192 positions for ~6 us of MFMA work
-        constexpr int kRing = 8;
-        u32x4d ra[kRing], rb[kRing];
+        // B operands through LDS (r4): read straight from global memory a B fragment is one 16-byte piece of a DIFFERENT position's row
+        // per lane — 32 rows = 64 cache lines per load instruction; staged, 32 consecutive threads copy 512 contiguous bytes of one row
+        // (chunks of 16 k-steps, double buffered, rows 528 bytes apart in LDS: an odd number of 16-byte units, conflict-free
+        // ds_read_b128) and the fragment is one LDS read.  A operands (weights, L2) stay on the kRing-deep register ring.  Same k order.
+        constexpr int kRing = 8, kChunks = 8;                                   // 7 x 16 + 9 k-steps
+        u32x4d stg[4];
+        auto stage_load = [&](int c) {
 #pragma unroll
-        for (int q = 0; q < kRing; ++q) {
-            ra[q] = *reinterpret_cast<const u32x4d*>(A.wp + ((size_t)q * 4 + wv) * 64 + lane);
-            rb[q] = *reinterpret_cast<const u32x4d*>(prow + 16 * q);
-        }
-        for (int k0 = 0; k0 < 121; k0 += kRing) {
+            for (int i = 0; i < 4; ++i) {
+                const int u = 256 * i + (int)threadIdx.x, row = u >> 5, col = u & 31;
+                const int prw = p0 + row < A.batch ? p0 + row : A.batch - 1;
+                stg[i] = u32x4d{0u, 0u, 0u, 0u};
+                if (32 * c + col < 242) stg[i] = *reinterpret_cast<const u32x4d*>(reinterpret_cast<const char*>(A.pin) + (size_t)prw * 3872 + (size_t)c * 512 + col * 16);
+            }
+        };
+        auto stage_store = [&](int buf) {
 #pragma unroll
-            for (int q = 0; q < kRing; ++q) {
-                const int k = k0 + q;
+            for (int i = 0; i < 4; ++i) {
+                const int u = 256 * i + (int)threadIdx.x, row = u >> 5, col = u & 31;
+                *reinterpret_cast<u32x4d*>(s_stage + buf * kStageBuf + row * 528 + col * 16) = stg[i];
+            }
+        };
+        u32x4d ra[kRing];
+#pragma unroll
+        for (int q = 0; q < kRing; ++q) ra[q] = *reinterpret_cast<const u32x4d*>(A.wp + ((size_t)q * 4 + wv) * 64 + lane);
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+        for (int c = 0; c < kChunks; ++c) {
+            if (c + 1 < kChunks) stage_load(c + 1);
+            const char* bb = s_stage + (c & 1) * kStageBuf + nn * 528 + kg * 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = 16 * c + q;
                 if (k < 121) {
                     bf16x8 x, y;
-                    __builtin_memcpy(&x, &ra[q], 16);
-                    __builtin_memcpy(&y, &rb[q], 16);
+                    __builtin_memcpy(&x, &ra[q % kRing], 16);
+                    const u32x4d yb = *reinterpret_cast<const u32x4d*>(bb + q * 32);
+                    __builtin_memcpy(&y, &yb, 16);
                     const int kn = k + kRing < 121 ? k + kRing : 120;          // (past the end: the last step again, never used)
-                    ra[q] = *reinterpret_cast<const u32x4d*>(A.wp + ((size_t)kn * 4 + wv) * 64 + lane);
-                    rb[q] = *reinterpret_cast<const u32x4d*>(prow + 16 * kn);
+                    ra[q % kRing] = *reinterpret_cast<const u32x4d*>(A.wp + ((size_t)kn * 4 + wv) * 64 + lane);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
                 }
             }
+            if (c + 1 < kChunks) stage_store((c + 1) & 1);
+            __syncthreads();
         }
         // a lane holds the outputs 32*wv + 16*kg + r of position nn (rows permuted at pack time)
         float mx = -3.0e38f;
