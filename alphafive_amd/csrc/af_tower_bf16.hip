@@ -67,6 +67,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 #endif
 }
 
+// ... with the sc0 sc1 bits: the load is served by L2, not by a line the CU's vector L1 may still hold from an earlier layer
+// (af_tower_persist: a workgroup re-reads what its own waves stored a layer ago; measured r3_19: the bits cost nothing)
+__device__ __forceinline__ void glds16c(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 sc1 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // ELU as max(x, min(exp(x), 1) - 1): x > 0 ? x : exp(x) - 1 with one v_max_f32 instead of compare + select and the clamp riding on
 // v_exp_f32 (r3_44).  exp(x) - 1 > x for x < 0 and the clamped exponential is exactly 1 for x >= 0; only for -3e-4 < x < 0 can the
 // rounding of v_exp_f32 put exp(x) - 1 below x, and the max then returns x, within 5e-8 of the true value (see af_conv_f16s.hip)
@@ -114,17 +122,30 @@ constexpr int kRounds = kPlaneB / (256 * 16);                           // 9 LDS
 constexpr uint32_t kLds0 = 256u;                                        // planes start here: unit -1 of a plane stays inside LDS
 constexpr uint32_t kZeroB = 33024u;                                     // all-zero LDS region the edge lanes read instead of a wrapped neighbour
 
-template <bool PROJ, int DEPTH>
-__global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];         // [256 B][g0][g1]([h])
+#ifdef AF_TOWER_TIMING
+// profiling build only (tools/probe_tower_timing.py): per wave and position, cycles of MFMA loop | wait for the next planes | barrier | epilogue
+__device__ unsigned long long g_tower_cyc[2][256][4][5];
+#define TT(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define TT(v)
+#endif
+// One convolution layer over this workgroup's positions.  CHAINED (af_tower_persist): called layer after layer inside one launch —
+// the layer starts once every wave's stores of the previous one have been acknowledged, and stages its planes with L1-bypassing loads.
+template <bool PROJ, int DEPTH, bool CHAINED>
+__device__ __forceinline__ void tower_layer(const TowerArgs& A, char* smem) {
     constexpr int NS = PROJ ? 80 : 72;
+    if (CHAINED) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem + kLds0;
 
     auto stage_round = [&](const char* src, int pos, uint32_t off, int r) {   // 4 KB piece r of a position's plane -> LDS
-        glds16(src + (size_t)pos * kPlaneB + threadIdx.x * 16u + r * 4096,
-               (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + off + wv * 1024u + r * 4096u)));
+        const char* gp = src + (size_t)pos * kPlaneB + threadIdx.x * 16u + r * 4096;
+        const uint32_t ld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + off + wv * 1024u + r * 4096u));
+        if (CHAINED) glds16c(gp, ld); else glds16(gp, ld);
     };
     auto stage = [&](const char* src, int pos, uint32_t off) {          // one position's plane -> LDS at byte offset off
 #pragma unroll
@@ -186,6 +207,9 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // first planes landed, zero region written
     __builtin_amdgcn_s_barrier();
 
+#ifdef AF_TOWER_TIMING
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+#endif
     for (int it = 0; pos < A.batch; pos += gridDim.x, ++it) {
         const uint32_t gcur = (it & 1) ? kPlaneB : 0u, gnxt = kPlaneB - gcur;
         const int nxt = pos + (int)gridDim.x;
@@ -197,6 +221,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
             bL[j] = edgeL[j] ? zb[j] : bC[j];
             bR[j] = edgeR[j] ? zb[j] : bC[j];
         }
+        TT(t0);
         f32x16 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -238,8 +263,11 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        TT(t1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the next position's planes have landed ...
+        TT(t2);
         __builtin_amdgcn_s_barrier();                                   // ... for every wave, and all are done with this one
+        TT(t3);
         // epilogue: bias, ELU, bf16, store.  The weight rows are packed so that a lane's 16 accumulator rows are the 16
         // consecutive couts 32*wave + 16*kg + r: two whole 8-channel units = two 16-byte stores per pixel tile, and the
         // 32 lanes of a k half cover 512 contiguous bytes.
@@ -256,6 +284,55 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
                 }
                 if (ok[j] && !(A.abl & 2)) *reinterpret_cast<bf16x8*>(o + (uint32_t)((4 * wv + 2 * kg + hf) * kPIX) * 16u + ob[j]) = v;
             }
+#ifdef AF_TOWER_TIMING
+        { TT(t4); tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += 1; }
+#endif
+    }
+#ifdef AF_TOWER_TIMING
+    if (!CHAINED && lane == 0 && blockIdx.x < 256) for (int q = 0; q < 5; ++q) g_tower_cyc[PROJ ? 1 : 0][blockIdx.x][wv][q] = tacc[q];
+#endif
+}
+
+template <bool PROJ, int DEPTH>
+__global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // [256 B][g0][g1]([h])
+    tower_layer<PROJ, DEPTH, false>(A, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// af_tower_persist (r4, A/B: af_tower_tune(3, 4)): the whole residual tower as ONE launch.  The 16 convolutions of the 8 blocks are
+// identical in shape and a convolution never looks outside its position, so a workgroup that keeps the same 32 positions from layer
+// to layer depends on no other workgroup: no grid-wide barrier, no flags — between two layers a wave waits for its own stores, the
+// workgroup meets at a barrier, the weight registers are reloaded (L2) and the position loop starts again on the other activation
+// buffer (staged with L1-bypassing loads).  Same arithmetic, same order: bit-identical to 16 x af_tower_conv.
+// MEASURED (profiles/r4_36): 4.217 ms per 8192-position pass against 4.198 (16 launches) — removing fifteen launches, their start-ups
+// and their device-wide barriers buys nothing: the phase stamps (r4_35) put 98 % of a position's MFMA loop at the MFMA issue rate and the
+// rest in the epilogue (2.3 k of 11.8 k cycles per position, VALU-bound: ~9 issue slots per output element), none of it between
+// positions or layers; the workgroups that finish a layer late are the same ones in every layer (XCD, profiles/r4_03), so a chain
+// without barriers ends with them just the same.  This is the single-launch experiment VERDICT r3 asked for, on the part of the
+// code base where it is easiest (no cout-split layer, one layer shape); the default stays 16 launches.
+struct PersistArgs {
+    char* x;                     // C8 bf16: block input / output (in place)
+    char* g;                     // C8 bf16: the block's intermediate
+    const uint4* const* w1;      // [blocks] A fragments of the first / second convolution (pack_tower)
+    const uint4* const* w2;
+    const float* const* b1;      // [blocks] biases
+    const float* const* b2;
+    int blocks, batch;
+    char* dump;
+};
+
+template <int D1, int D2>
+__global__ __launch_bounds__(256, 1) void af_tower_persist(PersistArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int b = 0; b < P.blocks; ++b) {
+        TowerArgs a;
+        a.batch = P.batch; a.abl = 0; a.dump = P.dump;
+        a.in = P.x; a.in2 = nullptr; a.w = P.w1[b]; a.bias = P.b1[b]; a.out = P.g;
+        if (b == 0) tower_layer<false, D1, false>(a, smem);            // (its input comes from an earlier launch)
+        else tower_layer<false, D1, true>(a, smem);
+        a.in = P.g; a.in2 = P.x; a.w = P.w2[b]; a.bias = P.b2[b]; a.out = P.x;
+        tower_layer<true, D2, true>(a, smem);
     }
 }
 
@@ -1050,6 +1127,7 @@ struct af_tower {
     std::vector<char> set;
     uint4* stem_w = nullptr;
     char* dump = nullptr;
+    char* d_ptrs = nullptr;       // af_tower_persist: [4][blocks] device pointers (w1, w2, b1, b2)
     float* stem_b = nullptr;
     float* heads_w = nullptr;
     float* heads_b = nullptr;
@@ -1169,6 +1247,7 @@ int af_tower_create(int32_t S, int32_t width, int32_t blocks, int32_t device, af
 #undef TW_ATTR
     TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv3<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv3<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_persist<8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     { void* q = nullptr; TW_HIP_OK(hipMalloc(&q, 4096)); t->dump = static_cast<char*>(q); }
@@ -1187,6 +1266,7 @@ void af_tower_destroy(af_tower* t) {
     for (auto p : t->b2) if (p) (void)hipFree(p);
     if (t->stem_w) (void)hipFree(t->stem_w);
     if (t->dump) (void)hipFree(t->dump);
+    if (t->d_ptrs) (void)hipFree(t->d_ptrs);
     if (t->stem_b) (void)hipFree(t->stem_b);
     if (t->heads_w) (void)hipFree(t->heads_w);
     if (t->heads_b) (void)hipFree(t->heads_b);
@@ -1206,6 +1286,7 @@ int af_tower_set_block(af_tower* t, int32_t b, const float* c1_w, const float* c
     TW_HIP_OK(hipSetDevice(t->device));
     const std::vector<uint16_t> p1 = pack_tower(c1_w, nullptr), p2 = pack_tower(c2_w, res_w);
     std::vector<float> bb(128);
+    if (t->d_ptrs) { (void)hipFree(t->d_ptrs); t->d_ptrs = nullptr; }     // (the pointer tables of af_tower_persist are rebuilt at the next forward)
     int rc = upload(&t->w1[b], p1.data(), p1.size() * 2);
     if (!rc) rc = upload(&t->w2[b], p2.data(), p2.size() * 2);
     const std::vector<uint16_t> q1 = pack_tower2(c1_w, nullptr), q2 = pack_tower2(c2_w, res_w);
@@ -1352,6 +1433,24 @@ int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_
     TW_HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (g_grid > 0) ncu = g_grid;
     const int grid = batch < ncu ? batch : ncu;
+    if (g_engine == 4) {         // r4: the whole tower as one launch
+        if (!t->d_ptrs) {        // device copies of the per-block pointer tables (once: the weight buffers are allocated per block)
+            const size_t n = (size_t)t->blocks;
+            std::vector<const void*> tab(4 * n);
+            for (size_t b = 0; b < n; ++b) { tab[b] = t->w1[b]; tab[n + b] = t->w2[b]; tab[2 * n + b] = t->b1[b]; tab[3 * n + b] = t->b2[b]; }
+            int rc = upload(&t->d_ptrs, tab.data(), tab.size() * sizeof(void*));
+            if (rc) return rc;
+        }
+        PersistArgs pa;
+        const void* const* tab = reinterpret_cast<const void* const*>(t->d_ptrs);
+        pa.x = static_cast<char*>(x_dev); pa.g = static_cast<char*>(g_dev);
+        pa.w1 = reinterpret_cast<const uint4* const*>(tab); pa.w2 = reinterpret_cast<const uint4* const*>(tab + t->blocks);
+        pa.b1 = reinterpret_cast<const float* const*>(tab + 2 * t->blocks); pa.b2 = reinterpret_cast<const float* const*>(tab + 3 * t->blocks);
+        pa.blocks = t->blocks; pa.batch = batch; pa.dump = t->dump;
+        hipLaunchKernelGGL((af_tower_persist<8, 6>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, pa);
+        TW_HIP_OK(hipGetLastError());
+        return AF_TOWER_OK;
+    }
     for (int b = 0; b < t->blocks; ++b) {
         TowerArgs a;
         a.batch = batch; a.abl = g_abl; a.dump = t->dump;
@@ -1388,6 +1487,14 @@ int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_
     TW_HIP_OK(hipGetLastError());
     return AF_TOWER_OK;
 }
+
+#ifdef AF_TOWER_TIMING
+int af_tower_debug_cycles(unsigned long long* host) {
+    TW_HIP_OK(hipDeviceSynchronize());
+    TW_HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tower_cyc), sizeof(unsigned long long) * 2 * 256 * 4 * 5));
+    return AF_TOWER_OK;
+}
+#endif
 
 int64_t af_tower_flops_per_position(const af_tower* t) {
     return (int64_t)2 * t->blocks * (128 * 128 * 9 * 2 + 128 * 128) * kNPIX;

@@ -1,4 +1,4 @@
-"""A/B of the bf16 tower's convolution kernels (af_tower_tune key 3): 0 = af_tower_conv, 2 = af_tower_conv3 (epilogue under the other
+"""A/B of the bf16 tower's convolution kernels (af_tower_tune key 3): 0 = af_tower_conv, 3 = conv3 for a block's first convolution (default), 4 = af_tower_persist (one launch), 2 = af_tower_conv3 (epilogue under the other
 tile pair's MFMAs).  8 blocks, B positions: outputs compared with each other and with the fp32 reference at B = 300, then the
 time of a tower pass at B = 8192 (interleaved rounds).  usage: python tools/probe_tower_engines.py"""
 import os, sys
@@ -36,9 +36,9 @@ for e in ENG:
     zero_ok = all(float(buf[:B, :, :S].float().abs().sum()) == 0.0 and float(buf[:B, :, S + S * S:].float().abs().sum()) == 0.0 for buf in (tw.x, tw.g))
     print("engine %d: err vs fp32 reference mean %.3e max %.3e | repeatable %s | zero borders intact %s | finite %s" % (
         e, err.mean().item(), err.max().item(), rep, zero_ok, bool(torch.isfinite(outs[e]).all())))
-if len(ENG) > 1:
-    d = (outs[ENG[0]] - outs[ENG[1]]).abs()
-    print("engine %d vs %d: max |diff| %.3e, identical elements %.2f %%" % (ENG[0], ENG[1], d.max().item(), 100.0 * (d == 0).float().mean().item()))
+for e in ENG[1:]:
+    d = (outs[ENG[0]] - outs[e]).abs()
+    print("engine %d vs %d: max |diff| %.3e, identical elements %.2f %%" % (ENG[0], e, d.max().item(), 100.0 * (d == 0).float().mean().item()))
 B = 8192
 hb = (torch.randn((B, 128, 11, 11), generator=g) * 0.5).to("cuda", torch.bfloat16)
 tw.load_nchw(hb)
