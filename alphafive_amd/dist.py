@@ -61,18 +61,29 @@ class PackedEpisodes(object):
     (af_engine_pack_episodes) in one of EpisodeGather's pinned host buffers.  Reading `n` / `plies` touches the 4-int header
     only; episodes() unpacks into raw episode dicts (game ids made global) — call it when the records are needed (a trainer's
     push), from any thread, before the buffer is recycled: the view stays valid through the collect() after the one that
-    returned it (the second one after it overwrites the buffer); copy() detaches it."""
-    __slots__ = ("buf", "max_eps", "rank", "games_per_rank")
+    returned it (the second one after it overwrites the buffer) and RAISES when read later than that (the ring slot carries a
+    generation counter); copy() detaches it."""
+    __slots__ = ("buf", "max_eps", "rank", "games_per_rank", "_gen", "_slot")
 
-    def __init__(self, buf, max_eps, rank, games_per_rank):
+    def __init__(self, buf, max_eps, rank, games_per_rank, gen=None, slot=None):
         self.buf, self.max_eps, self.rank, self.games_per_rank = buf, max_eps, rank, games_per_rank
+        self._gen, self._slot = gen, slot        # generation of the ring slot this view lives in (None: detached copy)
+
+    def _live(self):
+        """A view handed to a slower thread must not be read after its ring slot was given to a later step: the slot's
+        generation counter (bumped when the slot is re-used) must still be the one this view was made with."""
+        if self._slot is not None and self._slot[0] != self._gen:
+            raise RuntimeError("PackedEpisodes view read after its pinned ring slot was recycled (%d collects later); "
+                               "copy() it before handing it to a thread that may lag" % (self._slot[0] - self._gen))
 
     @property
     def n(self):
+        self._live()
         return int(self.buf[0])
 
     @property
     def plies(self):
+        self._live()
         return int(self.buf[1])
 
     def lengths(self):
@@ -80,10 +91,15 @@ class PackedEpisodes(object):
         return self.buf[4:4 + 4 * self.n].reshape(-1, 4)[:, 2]
 
     def copy(self):
-        return PackedEpisodes(self.buf.copy(), self.max_eps, self.rank, self.games_per_rank)
+        self._live()
+        out = PackedEpisodes(self.buf.copy(), self.max_eps, self.rank, self.games_per_rank)
+        self._live()                             # (recycled while copying: the copy is torn)
+        return out
 
     def episodes(self):
+        self._live()
         eps = _unpack_packed(self.buf, self.max_eps)
+        self._live()                             # (recycled while unpacking: the records are torn)
         if self.games_per_rank:
             for e in eps:
                 e["game"] += self.rank * self.games_per_rank
@@ -130,6 +146,7 @@ class EpisodeGather(object):
         self._turn = 0
         self._recv = None                 # rank 0: [world, cap] int32 on `device`
         self._host = [None] * self.RING   # rank 0: pinned [world, cap] int32
+        self._host_gen = [[0] for _ in range(self.RING)]      # per slot: bumped when the slot is handed to a new step
         self._host_turn = 0
         self.allocations = 0              # buffer (re)allocations so far: constant once the run has seen its widest step
         self.stats = {"steps": 0, "wall_s": 0.0, "host_s": 0.0, "comm_s": 0.0}
@@ -161,6 +178,9 @@ class EpisodeGather(object):
     def post(self, buf):
         """buf: the packed int32 buffer of this step (device tensor).  Issues the sizes exchange; returns at once."""
         w0, c0 = _time.perf_counter(), _time.thread_time()
+        if len(self._tickets) >= self.RING:      # the sizes ring has RING + 1 entries and a ticket owns one until it is gathered
+            raise RuntimeError("EpisodeGather.post: %d buffers posted without a collect() in between (at most %d)"
+                               % (len(self._tickets) + 1, self.RING))
         k = self._turn = (self._turn + 1) % len(self._sizes_host)
         used = (buf[1:2].to(torch.int64) * self.rec_ints + (4 + 5 * self.max_eps))          # stays on the device
         if self.collective:
@@ -199,6 +219,9 @@ class EpisodeGather(object):
             t["stage"] = 2
             return
         recv, host = self._ensure(width)
+        slot = self._host_gen[self._host_turn]
+        slot[0] += 1                              # views of the step that used this slot RING collects ago are stale from here on
+        t["slot"], t["gen"] = slot, slot[0]
         self._host_turn = (self._host_turn + 1) % self.RING
         if self.collective:
             self._comm(dist.gather, payload.contiguous(), [recv[r, :width] for r in range(self.world)], dst=0)
@@ -219,7 +242,7 @@ class EpisodeGather(object):
         if t["ev"] is not None:
             t["ev"].synchronize()
         h = t["host"].numpy()
-        out = [PackedEpisodes(h[r, :t["sizes"][r]], self.max_eps, r, self.games_per_rank) for r in range(self.world)]
+        out = [PackedEpisodes(h[r, :t["sizes"][r]], self.max_eps, r, self.games_per_rank, t["gen"], t["slot"]) for r in range(self.world)]
         if not unpack:
             return out
         eps = []

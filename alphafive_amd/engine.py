@@ -330,12 +330,14 @@ class SelfPlayEngine:
 
     pv_device: callable planes float32[G,3,S,S] (torch, on device) -> (policy[G,C], value[G])
     torch tensors on the same device — alphafive_amd.network.ResNet.eval_device, or a test stub.
+    weights_version: callable (or constant) naming the weight set pv_device evaluates with; only needed when pv_device
+    hides its net behind a wrapper (a lambda around net.eval_device): run_ticks_graph re-captures when it changes.
     value_f64: the arithmetic of the workers main.py actually runs (values through NetworkAPI pipes as python floats,
     networkAPI.py:72): W / Q in fp64.  Default False = the pv_fn path (self_play.py), SURVEY's parity target.
     """
 
     def __init__(self, cfg, num_games, pv_device, device=0, seed=0, first_game_id=0, training=True, node_cap=0,
-                 value_f64=False):
+                 value_f64=False, weights_version=None):
         import torch
         if not torch.cuda.is_available():
             raise EngineError("SelfPlayEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -351,6 +353,9 @@ class SelfPlayEngine:
         self.policy = torch.zeros((num_games, S * S), dtype=torch.float32, device=self.dev)
         self.value = torch.zeros((num_games,), dtype=torch.float32, device=self.dev)
         self.pv_device = pv_device
+        # run_ticks_graph keys its captured graph on this (a replay skips the Python wrapper that reloads weights): for a
+        # pv_device wrapped in a lambda pass weights_version=lambda: net.version
+        self._weights_version = self._resolve_weights_version(weights_version)
         if hasattr(pv_device, "bind_outputs"):       # the HIP net writes into our tensors: no copy per tick
             pv_device.bind_outputs(self.policy, self.value)
         self.ticks = 0
@@ -378,9 +383,29 @@ class SelfPlayEngine:
                 self.check()
 
     # ---- the steady-state loop as a HIP graph: n x (tree kernel -> leaf batch -> net) + the progress words, one launch ----
+    def _resolve_weights_version(self, explicit):
+        """-> callable giving the evaluator's weight version (what a captured graph is keyed on), or None when the evaluator
+        has no weights the engine could know about (a stub).  Sources, in order: the caller's weights_version=, the
+        evaluator's own .weights_version (net_hip.make_eval's closure, tower_hip), the `version` of the object a bound method
+        belongs to (pv_device=net.eval_device).  An evaluator that takes bind_outputs (i.e. one of ours, whose Python wrapper
+        is the only place that reloads weights) without any version source would replay stale weights silently: refuse."""
+        if explicit is not None:
+            return explicit if callable(explicit) else (lambda: explicit)
+        pv = self.pv_device
+        ver = getattr(pv, "weights_version", None)
+        if callable(ver):
+            return ver
+        owner = getattr(pv, "__self__", None)
+        if owner is not None and hasattr(owner, "version"):
+            return lambda: owner.version
+        if hasattr(pv, "bind_outputs"):
+            raise EngineError("run_ticks_graph: pv_device takes bind_outputs but exposes no weights_version; pass "
+                              "SelfPlayEngine(..., weights_version=lambda: net.version)")
+        return None
+
     def _graph_key(self, n):
-        ver = getattr(self.pv_device, "weights_version", None)
-        return (int(n), self.engine.params_key(), ver() if callable(ver) else None)
+        ver = self._weights_version
+        return (int(n), self.engine.params_key(), ver() if ver is not None else None)
 
     def run_ticks_graph(self, n=16, timed=False):
         """n ticks replayed as ONE HIP graph on the current stream (the tick kernel, the forward's 13 launches with the value

@@ -118,7 +118,13 @@ def make_eval(resnet):
         if state["net"] is not None and policy.shape[0] >= state["net"].max_batch:
             state["net"].bind_outputs(policy, value)
 
+    def close():
+        if state["net"] is not None:
+            state["net"].close()
+            state["net"] = None
+
     pv.bind_outputs = bind_outputs
+    pv.close = close
     pv.weights_version = lambda: getattr(resnet, "version", None)      # what a captured graph of this evaluator is keyed on
     return pv
 

@@ -83,8 +83,13 @@ class ResNet(object):
         self.variables = {}
         self._t = {}
         import threading
-        self._hip_eval = threading.local()       # eval_device(): one hand-written-kernel evaluator per calling thread
-        self._eval_lock = threading.Lock()       # eval() may be called from NetworkAPI's worker thread and the caller's (one set of buffers)
+        # eval_device(): one hand-written-kernel evaluator (packed weights + activation buffers for that thread's largest
+        # batch: ~350 KB per position at 11x11) per calling thread, so that NetworkAPI's worker thread and the caller's never
+        # share output buffers.  Kept in a registry keyed by thread: evaluators of threads that have ended are released the next
+        # time one is built, close() releases all of them.
+        self._hip_eval = {}
+        self._hip_eval_lock = threading.Lock()
+        self._eval_lock = threading.Lock()       # eval(): the returned views are copied to the host before the next call of ANY thread
         self.set_variables(random_variables(board_size, seed))
 
     # ---- weights ----
@@ -155,11 +160,23 @@ class ResNet(object):
         if self.device.type == "cuda":
             # one evaluator (kernel handle + output buffers) PER THREAD: NetworkAPI's worker thread calling eval() and a
             # SelfPlayEngine(pv_device=net.eval_device) on the caller's thread never share output buffers
-            ev = getattr(self._hip_eval, "fn", None)
-            if ev is None:
-                ev = self._hip_eval.fn = self.select_backend("hip")      # raises without libaf_net.so: no vendor-op fallback
-            return ev(x.contiguous())
+            return self._thread_evaluator()(x.contiguous())
         return self.eval_torch(x)
+
+    def _thread_evaluator(self):
+        import threading
+        me = threading.current_thread()
+        ent = self._hip_eval.get(me.ident)
+        if ent is not None and ent[0] is me:
+            return ent[1]
+        with self._hip_eval_lock:
+            for ident, (th, fn) in list(self._hip_eval.items()):
+                if not th.is_alive() or ident == me.ident:     # ended threads (and a recycled ident) give their device memory back
+                    fn.close()
+                    del self._hip_eval[ident]
+            fn = self.select_backend("hip")      # raises without libaf_net.so: no vendor-op fallback
+            self._hip_eval[me.ident] = (me, fn)
+        return fn
 
     def eval(self, inputs):
         """network.py:90-97: numpy float32[B,3,S,S] -> (prob[B,S*S], value[B]) numpy."""
@@ -213,3 +230,7 @@ class ResNet(object):
     def close(self):
         if self.api is not None:
             self.api.close()
+        with self._hip_eval_lock:                # every thread's evaluator: kernel handles, packed weights, activation buffers
+            for _, fn in self._hip_eval.values():
+                fn.close()
+            self._hip_eval.clear()

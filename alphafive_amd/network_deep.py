@@ -25,6 +25,11 @@ class _HipEvaluator(object):
         if policy.shape[0] >= self.net._tower.max_batch:
             self.net._tower.bind_outputs(policy, value)
 
+    def weights_version(self):
+        """What a captured graph of this evaluator is keyed on (SelfPlayEngine.run_ticks_graph): the tower packs its weights
+        once, at select_backend(); a new weight set means a new evaluator object."""
+        return id(self.net._tower)
+
 
 class DeepResNet(object):
     def __init__(self, board_size, blocks=8, width=128, device="cuda", dtype=torch.bfloat16, seed=0):

@@ -328,6 +328,58 @@ def extra_config_legs(timeout_s=240):
     return flat
 
 
+def spawn_ranks(n, timeout_s=None):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves — the same command line once
+    per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT in the environment, i.e. what
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would have set.  The children inherit stdout, and only
+    rank 0 prints the JSON line.  A rank that fails takes the others down with it (no hang on a half-formed group)."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AF_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+    rc, t0 = 0, time.time()
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+            if rc != 0 or (timeout_s and time.time() - t0 > timeout_s):
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)      # exactly the process groups started above
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+    if rc != 0:
+        raise SystemExit(rc if rc > 0 else 1)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -363,14 +415,20 @@ def main():
     if args.cpu_worker > 0:
         return _cpu_worker(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N` (the way the driver starts --gpus 1): be the launcher — one rank per
+        # GPU as child processes of this file (main.py:50-55 forks its own workers too); rank 0's line is the only output
+        return spawn_ranks(args.gpus)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (python -m torch.distributed.run --nproc-per-node %d "
+                         "bench.py --gpus %d) or plain `python bench.py --gpus %d`, which spawns its own ranks"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
     # AF_BENCH_SHARE_GPU=1 (test hook): all ranks share device 0 and talk over gloo, so the N>1 code path
@@ -435,19 +493,30 @@ def main():
     use_graph = args.loop == "graph"
     SAMPLE = 8                                        # eager, event-timed ticks per step in graph mode (~2 % of a step's ticks)
 
+    stepno = {"n": 0}
+
     def run_step(target):
         sample = use_graph and timing["on"]
+        # where in the step the eager sample sits rotates from step to step (replay 0, 5, 10, 15, 0, ... of ~26), so that the
+        # tick-kernel duration the forward's in-graph time is derived from is not always measured right after a hand-off
+        at, k = (stepno["n"] * 5) % 20, 0
+        stepno["n"] += 1
         while True:
             if use_graph:
                 sp.run_ticks_graph(args.poll, timed=timing["on"])         # returns at once
-                if sample:
+                if sample and k >= at:
                     # the sample that times the two kernels: eager launches bracketed by HIP events on the launch stream, inside
                     # the timed region, issued while the replay above keeps the device busy (no launch latency inside the
                     # brackets); everything else of the step runs from the graph
                     for _ in range(SAMPLE):
                         one_tick()
                     sample = False
+                k += 1
                 plies, _ = sp.progress_lagged()       # as of the previous replay: the device stays busy with the newest one
+                if plies >= target and sample:        # a short step: it still carries its sample
+                    for _ in range(SAMPLE):
+                        one_tick()
+                    sample = False
             else:
                 for _ in range(args.poll):
                     one_tick()
@@ -520,6 +589,7 @@ def main():
     sp.engine.tick_histogram(stream, reset=True)
     timing["on"] = True
     ticks0 = sp.ticks
+    gathered_at_t0 = gathered["episodes"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         target += G
@@ -527,6 +597,7 @@ def main():
     collect(last=True)                                # the last steps' episodes
     barrier()
     elapsed = time.perf_counter() - t0
+    gathered_in_region = gathered["episodes"] - gathered_at_t0
     timing["on"] = False
     ticks_timed = sp.ticks - ticks0
     ct1 = sp.counters()
@@ -543,6 +614,36 @@ def main():
     if world > 1:
         dist.all_reduce(eps_all, op=dist.ReduceOp.SUM)
     steady = eps_all.item() > 0
+    # what the process group really was (self-verifying N>1 line): an all-reduce of 1 over it, its backend, every rank's device
+    # and per-rank counts, so that "RCCL saw N ranks on N different GPUs" can be read off the line instead of the environment
+    ones = torch.ones(1, device=comm_dev, dtype=torch.float64)
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device": "cuda:%d" % local, "name": props.name,
+          "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "episodes_finished": int(ct1["episodes"] - ct0["episodes"]), "plies": int(plies), "elapsed_s": elapsed}
+    ranks_info = [me]
+    if world > 1:
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    ranks_seen = int(ones.item())
+    backend = dist.get_backend() if world > 1 else None
+    # untimed: drain the episodes still waiting on the devices (more than EP_CAP may finish in a step, and the gather runs one
+    # step behind), so that the line can state "rank 0 holds every episode the ranks finished": cumulative counts since engine
+    # creation on both sides (the engines' device counters vs the headers rank 0 received)
+    fin_total = torch.tensor([float(ct1["episodes"])], device=comm_dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(fin_total, op=dist.ReduceOp.SUM)
+    got_total = torch.zeros(1, device=comm_dev, dtype=torch.float64)
+    for _ in range(16):
+        got_total[0] = float(gathered["episodes"])
+        if world > 1:
+            dist.broadcast(got_total, src=0)
+        if got_total.item() >= fin_total.item():
+            break
+        hand_off()
+        collect(last=True)
+    gathered_total, finished_total = int(got_total.item()), int(fin_total.item())
 
     if rank == 0:
         d = {k: ct1[k] - ct0[k] for k in ct1}
@@ -562,6 +663,8 @@ def main():
         flop_pos = FLOP_PER_POSITION if cfg.board_size == 11 else net.flops_per_position()
         roof = net.roofline_info(pv)
         peak, dtype_name = roof.get("peak_tflops", PEAK_FP32_MFMA_TFLOPS), "f32"
+        if roof["backend"].startswith("hip") and "f16" in roof["backend"]:
+            dtype_name = "f32 (fp16x2 split operands: 3 fp16 MFMA products per MAC, fp32 accumulate)"
         if deep is not None:
             flop_pos, peak, dtype_name = deep.flops_per_position(), 2500.0, "bf16"   # dense bf16 MFMA peak
         net_tflops = G * flop_pos / (net_ms * 1e-3) / 1e12
@@ -623,7 +726,18 @@ def main():
                        "sims_per_ply_rank0": d["sims"] / max(1, d["plies"]),
                        "selects_per_sim": d["selects"] / max(1, d["sims"]),
                        "terminal_frac": d["terminals"] / max(1, d["sims"]),
-                       "episodes_gathered": gathered["episodes"], "episodes_finished_in_timed_region": int(eps_all.item()),
+                       "episodes_gathered": gathered_in_region, "episodes_finished_in_timed_region": int(eps_all.item()),
+                       # self-verification of the N>1 line: the process group as it really was, and rank 0's receipt of every
+                       # episode any rank finished since its engine was created (after an untimed drain of what was still queued)
+                       "ranks_seen": ranks_seen, "backend": backend if world > 1 else "none (single process)",
+                       "launcher": "bench.py spawn_ranks" if os.environ.get("AF_BENCH_SPAWNED") == "1" else
+                                   ("torch.distributed.run / external" if world > 1 else "single process"),
+                       "devices": ["%s %s %s" % (r["device"], r["name"], r["pci_bus_id"] or r["uuid"]) for r in ranks_info],
+                       "distinct_devices": len({(r["pci_bus_id"] or r["uuid"] or r["device"]) for r in ranks_info}),
+                       "per_rank": [{"rank": r["rank"], "episodes_finished": r["episodes_finished"], "plies": r["plies"],
+                                     "elapsed_s": r["elapsed_s"]} for r in ranks_info],
+                       "episodes_gathered_total": gathered_total, "episodes_finished_total_all_ranks": finished_total,
+                       "gathered_equals_finished": gathered_total == finished_total,
                        # rank 0's host time in the per-step hand-off (collect + pack launch + post), wall clock, inside the timed
                        # region: what the other ranks would wait for at max-over-ranks timing
                        "rank0_handoff_ms_per_step": 1e3 * handoff["s"] / max(1, handoff["n"])},
@@ -631,8 +745,10 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "traffic": traffic_net, "traffic_source": traffic_src, "ms_per_launch": net_ms,
                          "ms_per_launch_eager_sample": net_ms_eager,
-                         "ms_per_launch_source": ("HIP events around every graph replay of the timed region / ticks per replay - the tick kernel's "
-                                                  "event-timed launch duration (the forward as it runs inside the graph)") if graph_tick_ms else
+                         "ms_per_launch_source": ("DERIVED: HIP events around every graph replay of the timed region / ticks per replay (the primary "
+                                                  "measurement: time_split.graph_replay_ms_per_tick) - the tick kernel's eager event-timed launch "
+                                                  "duration (samples of 8 at a position that rotates through the step) = the forward as it runs "
+                                                  "inside the graph") if graph_tick_ms else
                                                  "HIP events around every eager forward of the timed region",
                          "flop_per_launch": G * flop_pos,
                          "note": "achieved = algorithmic (direct-convolution) FLOPs per launch / launch time; peak = dense MFMA peak of the "

@@ -72,6 +72,7 @@ def lib():
         L.afo_node_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), i32p, f32p, f32p, u8p]
         L.afo_tree_dump.argtypes = [vp, C.c_int, u64p, i32p, i32p, f32p, f32p, u8p]
         L.afo_stats.argtypes = [vp, u64p]
+        L.afo_tie_stats.argtypes = [vp, u64p]
         L.afo_tau.restype = C.c_double
         L.afo_tau.argtypes = [vp]
         L.afo_board_to_state.argtypes = [C.POINTER(C.c_int8), C.c_int, C.c_char_p, C.c_int]
@@ -302,6 +303,12 @@ class OraclePlayer:
         lib().afo_stats(self.h, _p(out, C.c_uint64))
         return dict(sims=int(out[0]), selects=int(out[1]), expands=int(out[2]), terminals=int(out[3]),
                     plies=int(out[4]))
+
+    def tie_stats(self):
+        """How often a uniform pick had more than one candidate so far (the only places where the RNG decides a search)."""
+        out = np.zeros(3, np.uint64)
+        lib().afo_tie_stats(self.h, _p(out, C.c_uint64))
+        return dict(select=int(out[0]), forced=int(out[1]), best=int(out[2]))
 
     def np_u32(self):
         return lib().afo_np_u32(self.h)

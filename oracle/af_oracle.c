@@ -292,6 +292,7 @@ struct afo_player {
     double tau;
     int pv_kind; afo_pv_fn fn; void* user; uint32_t salt, peak;
     uint64_t st_sims, st_selects, st_expands, st_terminals, st_plies;
+    uint64_t st_tie_select, st_tie_forced, st_tie_best;    /* picks among m > 1 candidates: the only places where the RNG decides */
 };
 
 static void board_to_bb(const int8_t* board, int C, bb_t* mine, bb_t* theirs) {
@@ -459,6 +460,7 @@ static int select_edge(afo_player* P, afo_node* nd, const int8_t* board, int is_
         for (int e = 0; e < L; ++e) if (nd->n[cells[e]] == 0) cand[m++] = e;
         if (m == 0) for (int e = 0; e < L; ++e) if (nd->n[cells[e]] == 1) cand[m++] = e;
         if (m > 0) {
+            if (m > 1) P->st_tie_forced++;
             int r = P->rng_mode == AFO_RNG_MT ? mt_np_randbelow(&P->np_rng, m)
                                               : (int)af_pick((uint32_t)m, sel, P->episode, AF_STREAM_PICK, P->k0, P->k1);
             return cells[cand[r]];
@@ -468,6 +470,7 @@ static int select_edge(afo_player* P, afo_node* nd, const int8_t* board, int is_
     for (int e = 1; e < L; ++e) if (scores[e] > mx) mx = scores[e];
     int cand[AFO_MAXC], m = 0;
     for (int e = 0; e < L; ++e) if (scores[e] == mx) cand[m++] = e;   /* :277-278 */
+    if (m > 1) P->st_tie_select++;
     int r = P->rng_mode == AFO_RNG_MT ? mt_np_randbelow(&P->np_rng, m)
                                       : (int)af_pick((uint32_t)m, sel, P->episode, AF_STREAM_PICK, P->k0, P->k1);
     return cells[cand[r]];
@@ -543,6 +546,7 @@ static int calc_policy(afo_player* P, afo_node* nd, const int8_t* board, int ran
     for (int e = 0; e < L; ++e) { pv[e] = (float)nd->n[cells[e]]; if (nd->n[cells[e]] > most) most = nd->n[cells[e]]; }
     int best[AFO_MAXC], nb = 0;
     for (int e = 0; e < L; ++e) if (nd->n[cells[e]] == most) best[nb++] = e;
+    if (nb > 1) P->st_tie_best++;
     const uint32_t ply = P->ply_ctr++;
     int bi = P->rng_mode == AFO_RNG_MT ? mt_py_randbelow(&P->py_rng, nb)            /* :102 always drawn */
                                        : (int)af_pick((uint32_t)nb, ply, P->episode, AF_STREAM_BEST, P->k0, P->k1);
@@ -676,6 +680,13 @@ int afo_tree_dump(const afo_player* P, int cap, uint64_t* keys, int32_t* sum_n, 
 
 void afo_stats(const afo_player* P, uint64_t* out) {
     out[0] = P->st_sims; out[1] = P->st_selects; out[2] = P->st_expands; out[3] = P->st_terminals; out[4] = P->st_plies;
+}
+
+/* how often a uniform pick had more than one candidate so far: score ties in select (:277-279), forced root visits (:264-276),
+ * max-visit ties in calc_policy (:101-102).  With all three at 0 a search is a function of the net alone — no RNG decided
+ * anything — which is what lets an eval-mode trace of the reference be compared with an engine that uses another generator. */
+void afo_tie_stats(const afo_player* P, uint64_t* out) {
+    out[0] = P->st_tie_select; out[1] = P->st_tie_forced; out[2] = P->st_tie_best;
 }
 
 uint32_t afo_np_u32(afo_player* P) { return mt_u32(&P->np_rng); }

@@ -92,6 +92,7 @@ int  afo_node_get(const afo_player* p, const char* state, int* sum_n, int32_t* n
 int  afo_tree_dump(const afo_player* p, int cap, uint64_t* keys, int32_t* sum_n, int32_t* n,
                    float* w, float* pr, uint8_t* f32);
 void afo_stats(const afo_player* p, uint64_t* out /* sims, selects, expands, terminals, plies */);
+void afo_tie_stats(const afo_player* p, uint64_t* out /* picks among > 1 candidates: score ties, forced root visits, max-visit ties */);
 double afo_tau(const afo_player* p);
 
 /* raw RNG access for unit tests of the MT restatement */

@@ -187,7 +187,7 @@ class _FakeAgent:
 
 
 def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, random_a=False, reset_every=None, pipe=False,
-             vbits=16, digest=False, **cfg_kw):
+             vbits=16, digest=False, sharp=0, **cfg_kw):
     cfg = mkcfg(board_size=S, goal=goal, simulation_per_step=sims, upper_simulation_per_step=upper, **cfg_kw)
     np.random.seed(seed)
     random.seed(seed)
@@ -200,7 +200,7 @@ def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, 
         api.start(reload=False)
         pl = Player(cfg, training=training, pipe=api.get_pipe(reload=False))
     else:
-        pl = Player(cfg, training=training, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak, vbits))
+        pl = Player(cfg, training=training, pv_fn=lambda x: pseudonet.pseudonet_np(x, salt, peak, vbits, sharp))
     state = pl.get_init_state()
     last, over, ply = None, False, 0
     C = S * S
@@ -230,7 +230,8 @@ def gen_mcts(path, S, goal, sims, upper, training, seed, salt, peak, max_plies, 
                random_a=np.asarray(random_a), states=np.array(states), actions=np.array(actions, np.int32),
                lasts=np.array(lasts, np.int32), visits=np.array(visits), policies=np.array(policies),
                has_policy=np.array(has_pol), taus=np.array(taus), np_next=np.asarray(np_next),
-               py_next=np.asarray(py_next), finished=np.asarray(over), pipe=np.asarray(bool(pipe)), vbits=np.asarray(vbits))
+               py_next=np.asarray(py_next), finished=np.asarray(over), pipe=np.asarray(bool(pipe)), vbits=np.asarray(vbits),
+               sharp=np.asarray(sharp))
     out.update(cfg_arrays(cfg))
     out.update(digest_tree(dump_tree(pl, S)) if digest else dump_tree(pl, S))
     if api is not None:
@@ -348,7 +349,23 @@ def gen_fullsize_cases(G):
     gen_mcts(G("mcts_s11_train_500.npz"), 11, 5, 500, 642, True, 17, 2024, 8192, 24, digest=True)
 
 
+def gen_sharp_cases(G):
+    """Eval-mode games (self_play.py:79-106 / choose_best_player.py:52: training=False) with the sharp pseudo-net
+    (tests/pseudonet.py, sharp=1, 24-bit values): no noise is applied in eval mode (player.py:247), so the only random
+    decisions are uniform picks among tied candidates (:277-279, :101-102) — and with priors that never coincide these
+    traces have (almost) none: tests/test_gpu_reference_fixtures.py compares the HIP Player's visit counts and moves with
+    THESE reference-generated arrays directly, no oracle in between.  11x11 at BASELINE's own 500 / 642."""
+    # salts picked (with the C oracle in MT mode, which replays these games bit for bit) among those whose game has no score tie at
+    # any select: 11x11 one max-visit tie (ply 12: changes the move picked, not the search), the other two none at all
+    gen_mcts(G("mcts_s11_eval_sharp.npz"), 11, 5, 500, 642, False, 31, 20312, 0, 121, vbits=24, sharp=1, digest=True)
+    gen_mcts(G("mcts_s6_eval_sharp.npz"), 6, 4, 100, 120, False, 32, 20251, 0, 36, vbits=24, sharp=1)
+    gen_mcts(G("mcts_s15_eval_sharp.npz"), 15, 5, 200, 260, False, 33, 20276, 0, 12, vbits=24, sharp=1, digest=True)
+
+
 def main():
+    if "--only-sharp" in sys.argv:
+        gen_sharp_cases(lambda name: os.path.join(HERE, name))
+        return
     if "--only-fullsize" in sys.argv:
         gen_fullsize_cases(lambda name: os.path.join(HERE, name))
         return
@@ -382,6 +399,7 @@ def main():
     gen_edge_cases(G)
     gen_pipe_cases(G)
     gen_fullsize_cases(G)
+    gen_sharp_cases(G)
 
 
 if __name__ == "__main__":

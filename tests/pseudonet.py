@@ -12,6 +12,12 @@ representable in fp32 and bit-identical on numpy / torch-CPU / torch-GPU.
 vbits (default 16, what the oracle's built-in copy has): value = ((mix32(..) & (2^vbits - 1)) - 2^(vbits-1)) / 2^vbits.
 With vbits = 24 the values use the whole fp32 mantissa, so an fp32 running sum of them rounds where an fp64 one does
 not: the pipe-path goldens (W as a python float, networkAPI.py:72) use that.
+
+sharp=1 (the tie-free traces, tests/golden/mcts_*_sharp.npz): policy_c = ((65536 + (m_c & 0xffff)) << ((m_c >> 16) & 7)) / 2^24 —
+integers below 2^24, so still exact in fp32, but with a 16-bit fraction (two cells of a position hardly ever share a prior:
+1.4 % of positions have such a pair at 11x11, against 7 pairs per position with the 10-bit k_c above) and priors spread over
+seven octaves, so that a search has a clear favourite and max-visit ties at the root are rare.  With no uniform pick among
+several candidates anywhere (oracle tie_stats() all zero) a search is a function of the net alone, whatever the generator.
 """
 import numpy as np
 
@@ -28,7 +34,7 @@ def _mix32_np(x):
     return x
 
 
-def pseudonet_np(planes, salt=0, peak=0, vbits=16):
+def pseudonet_np(planes, salt=0, peak=0, vbits=16, sharp=0):
     x = np.asarray(planes)
     B = x.shape[0]
     C = x.shape[2] * x.shape[3]
@@ -39,6 +45,8 @@ def pseudonet_np(planes, salt=0, peak=0, vbits=16):
     m = _mix32_np(h[:, None] ^ _mix32_np(c + 3001)[None, :])                            # [B,C]
     k = 1 + (m & 0x3FF) + np.where(((m >> 10) & 7) == 0, peak, 0)
     policy = k.astype(np.float32) * np.float32(1.0 / 131072.0)
+    if sharp:
+        policy = ((65536 + (m & 0xFFFF)) << ((m >> 16) & 7)).astype(np.float32) * np.float32(1.0 / 16777216.0)
     mv = _mix32_np(h ^ 0x9E3779B9)
     value = ((mv & ((1 << vbits) - 1)) - (1 << (vbits - 1))).astype(np.float32) * np.float32(1.0 / (1 << vbits))
     return policy, value
@@ -54,7 +62,7 @@ def _mix32_t(x):
     return x
 
 
-def pseudonet_torch(planes, salt=0, peak=0, vbits=16):
+def pseudonet_torch(planes, salt=0, peak=0, vbits=16, sharp=0):
     """planes: float32[B,3,S,S] torch tensor (any device) -> (policy[B,C], value[B]) float32."""
     import torch
     x = planes
@@ -68,6 +76,8 @@ def pseudonet_torch(planes, salt=0, peak=0, vbits=16):
     m = _mix32_t(h[:, None] ^ _mix32_t(c + 3001)[None, :])
     k = 1 + (m & 0x3FF) + torch.where(((m >> 10) & 7) == 0, torch.full_like(m, peak), torch.zeros_like(m))
     policy = k.to(torch.float32) * (1.0 / 131072.0)
+    if sharp:
+        policy = ((65536 + (m & 0xFFFF)) << ((m >> 16) & 7)).to(torch.float32) * (1.0 / 16777216.0)
     mv = _mix32_t(h ^ 0x9E3779B9)
     value = ((mv & ((1 << vbits) - 1)) - (1 << (vbits - 1))).to(torch.float32) * (1.0 / (1 << vbits))
     return policy, value

@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     afdist.broadcast_weights(net, src=0)
     digest = float(sum(np.abs(v).sum() for v in net.variables.values()))
     # the pipelined form bench.py uses: collect -> pack -> post per step, flush at the end; payloads lag two steps
-    M, R = 6, 2 * 4 + 2 * 36 + 2
+    M, R = 6, 2 * 2 * 4 + 2 * 36 + 2
     g = afdist.EpisodeGather(world, rank, dev, M, R, games_per_rank=1000)
     piped, lag = [], []
     for step in range(5):
@@ -165,3 +165,34 @@ def test_pack_unpack_roundtrip_empty_and_ragged():
         assert a["game"] == b["game"] and a["T"] == b["T"] and a["final_value"] == b["final_value"]
         for k in ("keys", "policies", "visits", "lasts", "actions"):
             assert (a[k] == b[k]).all()
+
+
+def test_a_stale_view_of_the_pinned_ring_raises_instead_of_reading_overwritten_episodes():
+    """collect(unpack=False) hands out views into a RING-deep pinned ring; a consumer that lags by RING collects must
+    get an error, not another step's episodes; copy() detaches a view; posting without collecting is bounded."""
+    import torch
+    g = afdist.EpisodeGather(1, 0, torch.device("cpu"), 4, 2 * 4 + 2 * 36 + 2, games_per_rank=0)
+
+    def step_buf(step):
+        eps = [_episode(0, step, 3 + step)]
+        return torch.from_numpy(afdist.pack_episodes(eps, 4))
+    views, copies = [], []
+    for step in range(6):
+        got = g.collect(unpack=False)
+        views += got
+        copies += [p.copy() for p in got]
+        g.post(step_buf(step))
+    views += g.flush(unpack=False)
+    assert len(views) == 6
+    assert [int(c.episodes()[0]["T"]) for c in copies] == [3, 4, 5, 6]             # detached copies stay what they were (the pipeline runs two steps behind)
+    assert views[-1].n == 1 and views[-2].n == 1 and views[-3].episodes()[0]["T"] == 6     # the newest RING views are live
+    for v in views[:3]:                                                             # older ones: their slots were re-used
+        with pytest.raises(RuntimeError, match="recycled"):
+            v.episodes()
+        with pytest.raises(RuntimeError, match="recycled"):
+            v.n
+    h = afdist.EpisodeGather(1, 0, torch.device("cpu"), 4, 2 * 4 + 2 * 36 + 2)
+    for step in range(afdist.EpisodeGather.RING):
+        h.post(step_buf(step))
+    with pytest.raises(RuntimeError, match="without a collect"):
+        h.post(step_buf(9))

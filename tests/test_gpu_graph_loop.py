@@ -118,6 +118,58 @@ def test_graph_loop_with_the_hand_written_net_follows_budget_and_weight_changes(
     b.close()
 
 
+@pytest.mark.parametrize("form", ["bound_method", "wrapped_with_version"])
+def test_graph_loop_follows_a_weight_update_behind_a_bound_method_or_wrapper(form):
+    """pv_device = net.eval_device (a bound method: no .weights_version of its own) or a lambda around it.
+    The graph key's weight component must still change with net.set_variables() — a replay skips the Python wrapper that reloads
+    the weights, so a key without it would keep playing on the stale set, silently."""
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.network import ResNet, random_variables
+    cfg = make_cfg(simulation_per_step=30, upper_simulation_per_step=40)
+    G = 64
+    nets = [ResNet(11, device="cuda") for _ in range(2)]
+    for nt in nets:
+        nt.load_npz(W)
+    if form == "bound_method":
+        a = SelfPlayEngine(cfg, G, nets[0].eval_device, device=0, seed=3)
+    else:
+        a = SelfPlayEngine(cfg, G, lambda x: nets[0].eval_device(x), device=0, seed=3, weights_version=lambda: nets[0].version)
+    b = SelfPlayEngine(cfg, G, nets[1].select_backend("hip"), device=0, seed=3)
+    for _ in range(4):
+        a.run_ticks_graph(8)
+    k0 = a._graph[0]
+    assert k0[2] == nets[0].version
+    for nt in nets:
+        nt.set_variables(random_variables(11, seed=5))
+    for _ in range(4):
+        a.run_ticks_graph(8)
+    assert a._graph[0] != k0 and a._graph[0][2] == nets[0].version
+    b.run_ticks(a.ticks)
+    a.check(), b.check()
+    assert a.counters() == b.counters()
+    for g in (0, G - 1):
+        ta, tb = a.engine.tree_dump(g), b.engine.tree_dump(g)
+        assert (ta["keys"] == tb["keys"]).all() and (ta["n"] == tb["n"]).all()
+        assert (ta["p"].view(np.uint32) == tb["p"].view(np.uint32)).all()          # priors of the NEW weights in both
+    a.close()
+    b.close()
+    for nt in nets:
+        nt.close()
+
+
+def test_graph_loop_refuses_an_evaluator_of_ours_without_a_weight_version():
+    from alphafive_amd.engine import SelfPlayEngine, EngineError
+
+    class Anonymous(object):                       # takes bind_outputs (so it owns weights and output tensors) but names no version
+        def __call__(self, x):
+            raise AssertionError("never called")
+
+        def bind_outputs(self, p, v):
+            pass
+    with pytest.raises(EngineError):
+        SelfPlayEngine(make_cfg(), 4, Anonymous(), device=0)
+
+
 @pytest.mark.parametrize("board,goal,value_f64", [(15, 5, False), (7, 4, True)])
 def test_graph_loop_on_the_other_instantiations(board, goal, value_f64):
     """af_tick_kernel<4, false> (15x15: four-word bitboards) and <2, true> (fp64 W / Q: the pipe path's arithmetic) inside the graph:

@@ -80,6 +80,35 @@ def test_bench_two_ranks_prints_one_consistent_line():
     # whole-job aggregate: both ranks' plies over the max-over-ranks time
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 96) < 0.25 * 2 * 96
     assert d["config"]["episodes_gathered"] >= 2 * 96 * 0.5  # rank 0 received episodes of both shards
+    _check_self_verifying_keys(d, 2, "gloo", "torch.distributed.run / external")
+
+
+def _check_self_verifying_keys(d, world, backend, launcher):
+    c = d["config"]
+    assert c["ranks_seen"] == world and c["backend"] == backend and c["launcher"] == launcher
+    assert len(c["devices"]) == world and len(c["per_rank"]) == world and [r["rank"] for r in c["per_rank"]] == list(range(world))
+    assert all(r["episodes_finished"] > 0 and r["plies"] > 0 for r in c["per_rank"])
+    # rank 0 holds every episode any rank finished (after the untimed drain), counted from the headers it received
+    assert c["gathered_equals_finished"] and c["episodes_gathered_total"] == c["episodes_finished_total_all_ranks"] > 0
+    assert sum(r["episodes_finished"] for r in c["per_rank"]) == c["episodes_finished_in_timed_region"]
+
+
+def test_plain_python_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` started the way the driver starts `--gpus 1` (no torch.distributed.run
+    around it, no RANK / WORLD_SIZE in the environment) launches its two ranks itself and prints ONE contract line that
+    carries what the process group really was."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", AF_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--games", "96", "--board", "6", "--sims", "30",
+                        "--upper", "40", "--steps", "36", "--warmup", "4", "--no-cpu-baseline"], cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 36 and d["warmup"] == 4 and d["value"] > 0
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 96) < 0.25 * 2 * 96
+    _check_self_verifying_keys(d, 2, "gloo", "bench.py spawn_ranks")
 
 
 def test_rccl_branch_runs_on_the_device(tmp_path):

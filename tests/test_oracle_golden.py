@@ -75,7 +75,8 @@ def test_mcts_trace_bit_exact(path):
     S = cfg.board_size
     pipe = bool(z.get("pipe", False))            # *_pipe.npz: the reference Player behind its NetworkAPI pipe (fp64 w / q)
     vbits = int(z.get("vbits", 16))
-    pv = None if vbits == 16 else (lambda x: pseudonet.pseudonet_np(x, int(z["salt"]), int(z["peak"]), vbits))
+    sharp = int(z.get("sharp", 0))               # *_sharp.npz: the tie-free eval-mode traces (tests/pseudonet.py)
+    pv = None if (vbits == 16 and not sharp) else (lambda x: pseudonet.pseudonet_np(x, int(z["salt"]), int(z["peak"]), vbits, sharp))
     pl = oracle.OraclePlayer(cfg, training=bool(z["training"]), rng_mode=oracle.RNG_MT, seed=int(z["seed"]), pv_fn=pv,
                              pseudo_salt=int(z["salt"]), pseudo_peak=int(z["peak"]), value_f64=pipe)
     for t in range(len(z["states"])):
@@ -87,6 +88,11 @@ def test_mcts_trace_bit_exact(path):
         else:
             assert pol is None
         assert pl.tau == float(z["taus"][t])
+    if sharp:
+        # the property tests/test_gpu_reference_fixtures.py rests on: no score tie at any select of these eval-mode games, so the
+        # searches are a function of the net alone and the HIP engine (another generator) can be held to these arrays directly
+        ties = pl.tie_stats()
+        assert ties["select"] == 0 and ties["forced"] == 0 and ties["best"] <= 0.2 * len(z["states"]), ties
     # both MT streams consumed exactly as many words as the reference did
     assert pl.np_u32() == int(z["np_next"])
     assert pl.py_u32() == int(z["py_next"])
