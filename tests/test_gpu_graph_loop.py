@@ -139,12 +139,13 @@ def test_graph_loop_follows_a_weight_update_behind_a_bound_method_or_wrapper(for
         a.run_ticks_graph(8)
     k0 = a._graph[0]
     assert k0[2] == nets[0].version
+    b.run_ticks(a.ticks)                           # the same ticks on the old weights ...
     for nt in nets:
         nt.set_variables(random_variables(11, seed=5))
     for _ in range(4):
         a.run_ticks_graph(8)
     assert a._graph[0] != k0 and a._graph[0][2] == nets[0].version
-    b.run_ticks(a.ticks)
+    b.run_ticks(a.ticks - b.ticks)                 # ... and on the new ones
     a.check(), b.check()
     assert a.counters() == b.counters()
     for g in (0, G - 1):
