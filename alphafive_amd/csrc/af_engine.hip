@@ -123,6 +123,12 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 #ifndef AF_TICK_NOISE_PASS0
 #define AF_TICK_NOISE_PASS0 1
 #endif
+#ifndef AF_TICK_NOISE_PAIR
+#define AF_TICK_NOISE_PAIR 0      // r5 A/B record (profiles/r5_03_tick_ab.txt): clean-up rounds with two attempts side by side — same bits, +5.5 % per launch: off
+#endif
+#ifndef AF_TICK_ROOT_TERM
+#define AF_TICK_ROOT_TERM 1       // r5: depth-0 terminal test: two-sided for EXTERNAL-mode roots, none in self-play (see the descent)
+#endif
 #ifndef AF_TICK_TERM_LAST
 #define AF_TICK_TERM_LAST 1
 #endif
@@ -803,9 +809,18 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         for (;;) {
             TK_T(tk_a);
             float tv;
-            // (the root of a simulation keeps the whole-board scan: an EXTERNAL-mode caller may hand over any position with no last move)
-            if ((AF_TICK_TERM_LAST && depth > 0 && P.goal <= 8) ? terminal_through_last<KW>(P, cm, ctb, last, inv_s16, lane, &tv)
-                                                                : terminal_test<KW, true>(P, cm, ctb, &tv)) {                 // :213-217
+            // The root of a simulation (depth 0).  Self-play: it was tested when the move that led to it was played (both sides, the
+            // episode ends there) or is the empty board, so the per-simulation scan of it can only say "not terminal": skipped (r5).
+            // EXTERNAL mode: a caller may hand over ANY position with no last move, also one in which the side to move already owns a
+            // line — utils.py:199-235 returns (True, 1.0) there, so the scan is the two-sided one (the one-sided scan let
+            // such a root be searched).  Inside a descent: through the last move only.
+            bool term;
+            if (AF_TICK_ROOT_TERM && depth == 0)
+                term = P.mode == AF_MODE_EXTERNAL ? (bool)terminal_test<KW, false>(P, cm, ctb, &tv) : false;
+            else
+                term = (AF_TICK_TERM_LAST && depth > 0 && P.goal <= 8) ? (bool)terminal_through_last<KW>(P, cm, ctb, last, inv_s16, lane, &tv)
+                                                                       : (bool)terminal_test<KW, true>(P, cm, ctb, &tv);
+            if (term) {                                                                                                   // :213-217
                 backup(depth, tv, 0);
                 ct[CT_TERMINALS]++; ct[CT_SIMS]++;
                 sims_left--;
@@ -918,6 +933,57 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                     ++tk_myit;
 #endif
                     todo = pend;
+#if AF_TICK_NOISE_PAIR
+                    // Clean-up rounds, two attempts side by side (r5).  A rejected cell continues with attempts 1, 2, ... of ITS counter
+                    // sequence (attempt a = words 2(a&1), 2(a&1)+1 of block a>>1), so whatever is evaluated speculatively, the variate is
+                    // the first accepted attempt = af_gamma_lt1's.  Slot A = the lane's first pending cell's next attempt; slot B = the
+                    // second pending cell's next attempt if the lane has one, else the SAME cell's following attempt (used only if A is
+                    // rejected).  Two independent dependency chains per iteration — what paid in round 0 — and the wave needs
+                    // ~1.2 clean-up iterations instead of ~3 (r4_15: the launch's slow waves spend 2/3 of a select here).  MEASURED
+                    // (profiles/r5_03_tick_ab.txt, steady-state mix, same digest): 0.1226-0.1234 ms per launch against 0.1162 — the
+                    // second chain doubles the instructions of iterations in which ~10 of 64 lanes are active, and in the bulk of a
+                    // launch four waves share a SIMD's issue slots; the latency it saves the lone waves of the tail is worth less.  Each slot
+                    // makes its own Philox block (no block is carried from one iteration to the next: the 8 registers of a cache cost
+                    // scratch at the kernel's 128-register budget, a block costs ~65 of an iteration's ~600 instructions).
+                    uint32_t itc[KW];
+#pragma unroll
+                    for (int q = 0; q < KW; ++q) itc[q] = 1u;
+                    while (todo) {
+#ifdef AF_TICK_TIMING
+                        ++tk_myit;
+#endif
+                        const int ka = __builtin_ctz(todo);
+                        const uint32_t rest = todo & (todo - 1u);
+                        const bool two = rest != 0u;
+                        const int kb = two ? __builtin_ctz(rest) : ka;
+                        uint32_t ia = 1u, ib = 1u;
+#pragma unroll
+                        for (int q = 0; q < KW; ++q) {
+                            ia = q == ka ? itc[q] : ia;
+                            ib = q == kb ? itc[q] : ib;
+                        }
+                        ib = two ? ib : ia + 1u;
+                        const af_u32x4 ra = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * ka), ia >> 1, k0, k1);
+                        const af_u32x4 rb = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * kb), ib >> 1, k0, k1);
+                        float XA, XB;
+                        const int okA = af_gamma_round(a_, inv_a, one_m_a, (ia & 1u) ? ra.v[2] : ra.v[0], (ia & 1u) ? ra.v[3] : ra.v[1], &XA);
+                        const int okB = af_gamma_round(a_, inv_a, one_m_a, (ib & 1u) ? rb.v[2] : rb.v[0], (ib & 1u) ? rb.v[3] : rb.v[1], &XB);
+                        // af_gamma_lt1: an attempt is accepted, or the variate is 0 after attempt 0xFFFF
+                        const bool endA = okA || ia == 0xFFFFu;
+                        const bool endB = okB || ib == 0xFFFFu;
+                        const double XAd = okA ? (double)XA : 0.0, XBd = okB ? (double)XB : 0.0;
+                        // one pending cell: B is that cell's next attempt and counts only if A was rejected
+                        const bool doneA = endA || (!two && endB);
+                        const double vA = endA ? XAd : XBd;
+                        const bool doneB = two && endB;
+#pragma unroll
+                        for (int q = 0; q < KW; ++q) {
+                            if (q == ka) { dd[q] = doneA ? vA : dd[q]; itc[q] = two ? ia + 1u : ia + 2u; }
+                            if (two && q == kb) { dd[q] = doneB ? XBd : dd[q]; itc[q] = ib + 1u; }
+                        }
+                        todo &= ~((doneA ? (1u << ka) : 0u) | (doneB ? (1u << kb) : 0u));
+                    }
+#else
                     uint32_t it = 1;
                     af_u32x4 r = rk[0];
 #pragma unroll
@@ -943,6 +1009,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                             ++it;
                         }
                     }
+#endif
 #else
                     uint32_t it = 0;
                     af_u32x4 r;
