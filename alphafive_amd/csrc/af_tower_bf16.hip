@@ -51,6 +51,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef AF_TOWER_VSLACK
 #define AF_TOWER_VSLACK 88       // architectural VGPRs left to everything that is not a weight fragment or the B-fragment ring
 #endif
+#ifndef AF_TOWER_EPI_SCALAR
+#define AF_TOWER_EPI_SCALAR 1    // af_tower_conv3: epilogue stages of two single-issue VALU instructions per MFMA gap (r5); 0 = r4's 2-vector stages
+#endif
 #ifndef AF_TOWER_ABL_NOLDS
 #define AF_TOWER_ABL_NOLDS 0     // profiling build: af_tower_conv without its B-fragment reads (results wrong by design)
 #endif
@@ -430,6 +433,49 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv3(TowerArgs A) {
     // there (unfenced it gathers four chunks in front of their store and reads a whole accumulator set in one burst)
     bf16x8 vst;
     f32x2 ex_[16], et_[16];
+#if AF_TOWER_EPI_SCALAR
+    // r5: the same epilogue as 16 chunks x 8 stages of TWO single-issue VALU instructions, one stage behind every MFMA of the other
+    // pair's phase (128 of its 144 [160]).  r4's stages used 2-vector arithmetic (v_pk_add_f32 / v_pk_mul_f32): a packed fp32
+    // instruction beside an MFMA costs ~+22-26 cycles of a 32-cycle gap (MI355X_MICROARCH.md, "price of one filler beside MFMAs"),
+    // i.e. 48 stages x ~20 cycles per phase gave back what hiding the epilogue had won (254.5 vs 258.3 us per layer).  Plain
+    // v_add / v_mul / v_exp / v_max / v_cvt_pk_bf16 fillers are hidden up to ~5 per gap.  The opaque asm("" : "+v") after each
+    // result keeps hipcc's SLP vectoriser from re-packing the two elements of a chunk.
+    float e0_[16], e1_[16], t0_[16], t1_[16];
+    auto epi_stage = [&](int jp0, int c, int k, char* o) {
+        const int j = jp0 + (c >> 3), q = c & 7, hf = q >> 2, e = 2 * (q & 3);
+#define AF_OPAQUE(x) asm volatile("" : "+v"(x))
+        if (k == 0) {
+            float a0;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a0) : "a"(acc[j][8 * hf + e]));
+            e0_[c] = a0 + bias_r[8 * hf + e]; AF_OPAQUE(e0_[c]);
+        } else if (k == 1) {
+            float a1;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a1) : "a"(acc[j][8 * hf + e + 1]));
+            e1_[c] = a1 + bias_r[8 * hf + e + 1]; AF_OPAQUE(e1_[c]);
+        } else if (k == 2) {
+            float t = e0_[c] * 1.44269504088896341f; AF_OPAQUE(t);
+            t0_[c] = fminf(fmaxf(__builtin_amdgcn_exp2f(t), 0.0f), 1.0f); AF_OPAQUE(t0_[c]);
+        } else if (k == 3) {
+            float t = e1_[c] * 1.44269504088896341f; AF_OPAQUE(t);
+            t1_[c] = fminf(fmaxf(__builtin_amdgcn_exp2f(t), 0.0f), 1.0f); AF_OPAQUE(t1_[c]);
+        } else if (k == 4) {
+            // (v_max_f32 by hand: fmaxf() comes with a canonicalising v_max x, x, x of each input in IEEE mode — three instructions)
+            const float m = t0_[c] - 1.0f;
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(e0_[c]) : "v"(e0_[c]), "v"(m));
+        } else if (k == 5) {
+            const float m = t1_[c] - 1.0f;
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(e1_[c]) : "v"(e1_[c]), "v"(m));
+        } else if (k == 6) {
+            vst[e] = (__bf16)e0_[c]; vst[e + 1] = (__bf16)e1_[c];
+        } else if ((q & 3) == 3) {
+            char* dst = o + (uint32_t)((4 * wv + 2 * kg + hf) * kPIX) * 16u + ob[j];
+            if (j == 3) dst = ok[3] ? dst : A.dump + threadIdx.x * 16u;            // (only tile 3 has lanes past the board)
+            *reinterpret_cast<bf16x8*>(dst) = vst;
+        }
+#undef AF_OPAQUE
+    };
+    (void)ex_; (void)et_;
+#else
     auto epi_stage = [&](int jp0, int c, int k, char* o) {
         const int j = jp0 + (c >> 3), q = c & 7, hf = q >> 2, e = 2 * (q & 3);
         if (k == 0) {
@@ -454,6 +500,9 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv3(TowerArgs A) {
             }
         }
     };
+#endif
+    constexpr int kEpiK = AF_TOWER_EPI_SCALAR ? 8 : 3;                   // stages per chunk
+    constexpr int kEpiStride = AF_TOWER_EPI_SCALAR ? 1 : 2;              // one stage every kEpiStride MFMAs, from the 4th of a phase on
 
     auto position = [&](auto first_tag, int it, int pos_) {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -493,11 +542,11 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv3(TowerArgs A) {
             // the other pair's epilogue, one chunk every 8 MFMAs from the 5th on (16 chunks inside the phase's first 132 MFMAs)
             {
                 const int q = m < NH ? m : m - NH;
-                if (q >= 3 && (q - 3) % 2 == 0 && (q - 3) / 2 < 48 && (m >= NH || !FIRST)) {
-                    const int st_ = (q - 3) / 2;
+                if (q >= 3 && (q - 3) % kEpiStride == 0 && (q - 3) / kEpiStride < 16 * kEpiK && (m >= NH || !FIRST)) {
+                    const int st_ = (q - 3) / kEpiStride;
                     __builtin_amdgcn_sched_barrier(0);
-                    if (m >= NH) epi_stage(0, st_ / 3, st_ % 3, o);                // pair A of this position, under phase B
-                    else epi_stage(2, st_ / 3, st_ % 3, o_prev);                   // pair B of the previous position, under phase A
+                    if (m >= NH) epi_stage(0, st_ / kEpiK, st_ % kEpiK, o);        // pair A of this position, under phase B
+                    else epi_stage(2, st_ / kEpiK, st_ % kEpiK, o_prev);           // pair B of the previous position, under phase A
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -526,7 +575,7 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv3(TowerArgs A) {
 #pragma unroll
     for (int c = 0; c < 16; ++c)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) epi_stage(2, c, k, o_prev);
+        for (int k = 0; k < kEpiK; ++k) epi_stage(2, c, k, o_prev);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -231,6 +231,30 @@ def test_selfplay_episodes_match_oracle(S, goal, sims, upper, G, node_cap):
     sp.close()
 
 
+@pytest.mark.parametrize("owner", ["side_to_move", "opponent"])
+def test_get_action_on_a_decided_root_fails_like_the_reference(owner):
+    """an EXTERNAL-mode caller may hand over ANY position.  A root in which a line is already complete — for the
+    opponent (value -1) or for the side to move (utils.py:199-235 returns (True, 1.0) there too) — is terminal in every simulation
+    (player.py:213-217), so nothing is ever expanded and the reference's get_action dies in calc_policy on an empty node; the
+    engine reports AF_ERR_NO_ROOT ("get_action on a finished position") and must not search such a root."""
+    from alphafive_amd import engine as eng
+    from alphafive_amd.player import Player
+    S = 6
+    board = np.zeros((S, S), np.int8)
+    board[2, 0:4] = 1 if owner == "side_to_move" else -1      # goal = 4 in a row
+    board[4, 0:3] = -1 if owner == "side_to_move" else 1
+    state = oracle.board_to_state(board)
+    assert oracle.is_game_over(board, 4) == (True, 1.0 if owner == "side_to_move" else -1.0)
+    cfg = make_cfg(board_size=S, goal=4, simulation_per_step=20, upper_simulation_per_step=30)
+    pl = Player(cfg, training=False, pv_fn=lambda x: pseudonet.pseudonet_np(x, 3, 0), seed=1, game_id=0)
+    with pytest.raises(eng.EngineError, match="finished position"):
+        pl.get_action(state, last_action=None)
+    pl.close()
+    orc = oracle.OraclePlayer(cfg, training=False, rng_mode=oracle.RNG_PHILOX, seed=1, game_id=0, pseudo_salt=3, pseudo_peak=0)
+    with pytest.raises(Exception):
+        orc.get_action(state, None)
+
+
 def test_engine_fails_loudly_on_full_store():
     from alphafive_amd import engine as eng
     import torch
