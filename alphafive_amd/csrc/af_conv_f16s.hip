@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -248,26 +249,31 @@ struct F16sArgs {
     char* hx;             // value: [position][hi|lo][128 pixels][4] fp16; policy: [position][hi|lo][128 pixels][16] fp16
     float inv_scale_h;
     int batch, WP, PP;
+    int gx0;              // af_conv_f16s_h15: workgroups (per blockIdx.y) of the half-0 class
+    char* stash;          // af_conv_f16s_h15 -> af_corner_f16s: [board][slab of the stream][hi|lo][4 unit rows][pixels 208, 209, 223, 224] units
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
 };
 
-// DIST: prefetch distance of this instantiation (default kDist); WPE: waves per SIMD = workgroups per CU.  WPE = 2 (r3) is for the
-// narrow layers whose whole register need fits 256: with DIST = 1 the ring is 3 slots (74 KB per workgroup), two workgroups share
-// a CU and one's epilogue / barriers / waits run under the other's MFMAs.
-template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST = kDist, int WPE = 1>
-__global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void af_conv_f16s(F16sArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// The kernel body.  NTW: pixel tiles per wave (4 / PS for a whole pseudo-position).  HSEL (r5, 15x15 only): -1 = the workgroups of
+// this launch take both halves of the boards alternately (bx even / odd, the r3 scheme); 0 / 1 = the `gxw` workgroups of this CLASS
+// (index bx) take that half of EVERY board — af_conv_f16s_h15 runs a class of NTW = 4 workgroups on half 0 (pixels 0..127) next to
+// a class of NTW = 3 workgroups on half 1 (pixels 128..223: three full tiles; pixel 224, the fourth tile's only pixel, is left to
+// af_corner_f16s) in one launch.
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST, int WPE, int NTW, int HSEL>
+__device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const int bx, const int gxw) {
     using L = Lay<G>;
     constexpr uint32_t kRowH = L::kRowH, kHalfH = L::kHalfH, kSlabH = L::kSlabH, kRowL = L::kRowL, kHalfL = L::kHalfL, kSlotL = L::kSlotL;
     constexpr uint32_t kZoff = Lds<G, DIST>::kZoff, kBiasOff = Lds<G, DIST>::kBiasOff, kScrOff = Lds<G, DIST>::kScrOff;
     constexpr int kDist = DIST, kRing = DIST + 2;                             // (shadow the file-level default)
     constexpr int NPC = G::NPC, HV = G::HALVES;
-    constexpr int NT = 4 / PS;                    // pixel tiles per wave
+    constexpr int NT = NTW;                       // pixel tiles per wave
+    static_assert(HSEL < 0 || (HV == 2 && PJ == 0 && HD == 0 && !OUT32), "half classes: plain 15x15 layers only");
+    static_assert(NT % KS == 0 || PJ == 0, "an odd tile count under a k-split has no projection exchange");
     constexpr int C16 = 2 / KS;                   // 16-channel k-steps per slab and wave
     constexpr int ITP = C16, ITM = 9 * C16;       // items (k-step x tap) per projection / main slab
     constexpr int NIT = NSP * ITP + NSM * ITM;    // items per position and wave
     constexpr int SPP = NSP + NSM;                // slabs per position
-    constexpr int NFIN = NT / KS;                 // tiles a wave finishes (epilogue) after the k-split exchange
+    constexpr int NFIN = NT / KS;                 // tiles a wave finishes (epilogue) after the k-split exchange (odd NT: see OWN below)
     static_assert(CT * KS * PS == 4 && NT >= KS, "4 waves");
     static_assert(PJ == 0 || NSP == 0, "a producer / consumer of the separate projection has no projection slabs");
     constexpr int NPW = PJ == 1 ? NSM * C16 : 0;  // projection items (centre tap of every k-step)
@@ -280,22 +286,25 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     // 0 .. NFIN-1 and the ones it hands to its partner its slots NFIN .. NT-1: exchange, combine and epilogue are unconditional
     // straight-line code (with "tile jj / NFIN == ks" they were branches on ks, and every accumulator made a round trip through
     // v_accvgpr_write / v_accvgpr_read at the merge points)
-    const int rot = KS == 2 ? ks * (NT / KS) : 0;
+    // Odd NT (r5: the 3-tile half of a 15x15 board): wave ks = 0 finishes (NT + 1) / 2 tiles, wave ks = 1 the other NT / 2; the slot in
+    // the middle is the only one whose role depends on the wave (a scalar branch in exchange / combine / epilogue).
+    const int rot = KS == 2 ? ks * ((NT + 1) / 2) : 0;
+#define AF_OWN(jj) (KS == 1 || (jj) < NT / 2 || ((jj) < (NT + 1) / 2 && ks == 0))
     const int ctg = (int)blockIdx.y * CT + ct, nso = (int)gridDim.y * CT;
     const uint32_t lds = (uint32_t)(uintptr_t)smem;
 
     // pseudo-position q = HALVES * position + half; this workgroup takes q0, q0 + gridDim.x, ... (gridDim.x is a multiple of
     // HALVES, so the half — and with it every lane's pixel, window and edge flags — is fixed for the whole launch)
-    const int nq = A.batch * HV;
+    const int nq = HSEL >= 0 ? A.batch : A.batch * HV;
     // Which pseudo-positions a workgroup takes (r4): consecutive workgroup ids land on consecutive XCDs, so with q0 = blockIdx.x the 32
     // workgroups of XCD k would walk the positions = k (mod 8) only — one residue class of the activation addresses per XCD, all in
     // step — and the XCDs finish 3 % apart, launch after launch, even ones late (profiles/r4_03).  With the swizzle XCD k takes the
     // CONTIGUOUS positions 32k .. 32k+31 (+ gridDim.x per pass): every XCD touches every address residue.  A position's result does
     // not depend on which workgroup computes it (same bits); gridDim.x / 8 is a multiple of HALVES whenever the swizzle is used.
-    int qpos = blockIdx.x;
-    if (AF_F16S_XCD_SWIZZLE && (gridDim.x & (8 * HV - 1)) == 0) qpos = (int)(blockIdx.x >> 3) + (int)(gridDim.x >> 3) * (int)(blockIdx.x & 7);
+    int qpos = bx;
+    if (AF_F16S_XCD_SWIZZLE && (gxw & (8 * (HSEL >= 0 ? 1 : HV) - 1)) == 0) qpos = (bx >> 3) + (gxw >> 3) * (bx & 7);
     if (qpos >= nq) return;
-    const int hv = HV == 1 ? 0 : qpos % HV;
+    const int hv = HSEL >= 0 ? HSEL : (HV == 1 ? 0 : qpos % HV);
     const uint32_t wsrc = G::wbase(hv) * 16u;          // byte offset of the half's window inside a unit row (HBM)
     AF_T(t_entry);
 #ifdef AF_F16S_TIMING
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     // order — long slabs first, so that the epilogue's stores have more time before the next wait on vmcnt — measured
     // 1.58 vs 1.55 ms per forward and moved |dp| from 6.0e-6 to 8.1e-6)
     auto slab_src = [&](int qq, int j) -> const char* {             // (qq: pseudo-position)
-        const int p = HV == 1 ? qq : qq / HV;
+        const int p = (HV == 1 || HSEL >= 0) ? qq : qq / HV;
         if (AF_F16S_MAIN_FIRST) return (j < NSM ? A.in + ((size_t)p * NSM + j) * kSlabH : A.in2 + ((size_t)p * NSP + (j - NSM)) * kSlabH) + wsrc;
         return (j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabH : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabH) + wsrc;
     };
@@ -325,10 +334,10 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     // slab number `idx` of the stream this workgroup consumes (pseudo-positions q0, q0 + gridDim.x, ...; SPP slabs each)
     const int q0 = qpos;
     auto stream_src = [&](uint32_t idx) -> const char* {
-        const int p = q0 + (int)(idx / SPP) * (int)gridDim.x, j = (int)(idx % SPP);
+        const int p = q0 + (int)(idx / SPP) * gxw, j = (int)(idx % SPP);
         return slab_src(p, j);
     };
-    const uint32_t nslabs = (uint32_t)((nq - q0 + (int)gridDim.x - 1) / (int)gridDim.x) * SPP;
+    const uint32_t nslabs = (uint32_t)((nq - q0 + gxw - 1) / gxw) * SPP;
 
     // Start-up (5-8 us of every launch, r2_39): the longest latencies first — the first kDist slabs (HBM -> LDS-DMA), then the
     // weights (L2) — and under them the LDS zeroing: only what LDS-DMA never writes (slack, the pad units 0..7 and 136..143 of
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     bool ok[NT], edgeL[NT], edgeR[NT];
 #pragma unroll
     for (int jj = 0; jj < NT; ++jj) {
-        const int n = 128 * hv + 32 * (ps * NT + ((jj + rot) & (NT - 1))) + nn;
+        const int n = 128 * hv + 32 * (ps * NT + ((jj + rot) % NT)) + nn;
         ok[jj] = n < G::NPIX;
         const int nc = ok[jj] ? n : 128 * hv;                                // (an invalid lane works on the half's first pixel)
         pix[jj] = nc;
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
     // the one of slab t-2, which every wave left before the barrier inside slab t-1.)
     // XPOS: the prefetch also crosses the position boundary (the fragments stay live through the epilogue) — not where
     // weights + accumulators already fill the register file (4 pixel tiles and >= 288 weight registers)
-    constexpr bool XPOS = !(NT == 4 && NIT >= 36);
+    constexpr bool XPOS = !(NT >= 3 && NIT >= 36);
     h8 fr[2][NT][2];
 #define AF_FIRST_ITEM(slot)                                                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                          \
@@ -452,8 +461,8 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
 #ifdef AF_F16S_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (; qpos < nq; qpos += gridDim.x) {
-        const int pos = HV == 1 ? qpos : qpos / HV;
+    for (; qpos < nq; qpos += gxw) {
+        const int pos = (HV == 1 || HSEL >= 0) ? qpos : qpos / HV;
         AF_T(tp0);
         if (!XPOS) { AF_FIRST_ITEM(cur) }
 #undef AF_FIRST_ITEM
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
             const int ibase = proj ? pslab * ITP : NSP * ITP + ms * ITM;
             const int seq = AF_F16S_MAIN_FIRST ? (proj ? NSM * ITM + pslab * ITP : ms * ITM) : ibase;
             // slab t + kDist of the stream: j is static (the loop is unrolled), so which position / slab that is costs no division
-            const int npos = qpos + ((j + kDist) / SPP) * (int)gridDim.x;
+            const int npos = qpos + ((j + kDist) / SPP) * gxw;
             const bool more = npos < nq && !(A.abl & 1);
             const char* nsrc = slab_src((A.abl & 4) ? q0 : (more ? npos : qpos), (j + kDist) % SPP);   // abl bit 2: the first position's slabs again (L2-hot)
             const uint32_t nx1 = cur + kSlotL == kRing * kSlotL ? 0u : cur + kSlotL;     // slot of slab t+1
@@ -499,6 +508,16 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
                 bC[jj] = (AF_F16S_ZPAD && !ok[jj]) ? zb[jj] : lb[jj] + cur;
                 bL[jj] = edgeL[jj] ? zb[jj] : bC[jj];
                 bR[jj] = edgeR[jj] ? zb[jj] : bC[jj];
+            }
+            if (HSEL == 1 && wv == (j & 3) && blockIdx.y == 0 && lane < 32) {
+                // The corner pixel's operands, while the slab is in LDS (r5): the four on-board taps of pixel 224 are pixels 208, 209,
+                // 223, 224 = window units 128, 129, 143, 144 of each of the slab's 8 unit rows — 32 units of 16 bytes, copied to a compact
+                // buffer that af_corner_f16s reads as contiguous 512-byte rows (read from the S32 tensor they are 3 cache lines of 128
+                // bytes per row for 64 useful bytes, 50 MB per layer: 25-45 us per corner launch, profiles/r5_09).  The store is younger
+                // than the LDS-DMA pieces the counted vmcnt waits are about: it can only make those waits more conservative.
+                const uint32_t u = (uint32_t)(lane & 3), un = (u < 2 ? 128u + u : 141u + u);
+                const uint4 q = *reinterpret_cast<const uint4*>(smem + kLds0 + cur + (uint32_t)(lane >> 4) * kHalfL + (uint32_t)((lane >> 2) & 3) * kRowL + un * 16u);
+                *reinterpret_cast<uint4*>(A.stash + (((size_t)pos * SPP + j) * 32 + lane) * 16) = q;
             }
 #pragma clang loop unroll(full)
             for (int it = 0; it < NI; ++it) {
@@ -594,10 +613,10 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
 #define AF_EXCHANGE(ACC, SCR)                                                                                              \
     {                                                                                                                      \
         _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                                \
-            if (jj >= NFIN) {                                                                                              \
+            if (!AF_OWN(jj)) {                                                                                             \
                 _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
                     f32x4 v = {ACC[jj][4 * q], ACC[jj][4 * q + 1], ACC[jj][4 * q + 2], ACC[jj][4 * q + 3]};                \
-                    *reinterpret_cast<f32x4*>((SCR) + (uint32_t)(((jj + rot) & (NT - 1)) * 4 + q) * 1024u + lane * 16u) = v; \
+                    *reinterpret_cast<f32x4*>((SCR) + (uint32_t)(((jj + rot) % NT) * 4 + q) * 1024u + lane * 16u) = v;     \
                 }                                                                                                          \
             }                                                                                                              \
         }                                                                                                                  \
@@ -605,9 +624,9 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
 #define AF_COMBINE(ACC, SCR)                                                                                               \
     {                                                                                                                      \
         _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                                \
-            if (jj < NFIN) {                                                                                               \
+            if (AF_OWN(jj)) {                                                                                              \
                 _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                            \
-                    const f32x4 v = *reinterpret_cast<const f32x4*>((SCR) + (uint32_t)(((jj + rot) & (NT - 1)) * 4 + q) * 1024u + lane * 16u); \
+                    const f32x4 v = *reinterpret_cast<const f32x4*>((SCR) + (uint32_t)(((jj + rot) % NT) * 4 + q) * 1024u + lane * 16u); \
                     ACC[jj][4 * q] += v[0]; ACC[jj][4 * q + 1] += v[1]; ACC[jj][4 * q + 2] += v[2]; ACC[jj][4 * q + 3] += v[3]; \
                 }                                                                                                          \
             }                                                                                                              \
@@ -631,8 +650,8 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
         if (PJ == 1) {                                                       // the projection, fp32, in accumulator layout
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
-                if (KS == 2 && jj >= NFIN) continue;
-                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + ps * NT + ((jj + rot) & (NT - 1))) * 4) * 64 + lane;
+                if (!AF_OWN(jj)) continue;
+                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + ps * NT + ((jj + rot) % NT)) * 4) * 64 + lane;
                 if (!(A.abl & 2)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -654,8 +673,7 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
         }
 #pragma unroll
         for (int jj = 0; jj < NT; ++jj) {
-            const bool mine = KS == 1 || jj < NFIN;
-            if (!mine) continue;
+            if (!AF_OWN(jj)) continue;
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -752,6 +770,157 @@ __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, W
         if (wv == 0) { g_f16s_wall[layer][blockIdx.x + 256 * blockIdx.y][0] = wall_entry; g_f16s_wall[layer][blockIdx.x + 256 * blockIdx.y][1] = wall_clock64(); }
     }
 #endif
+#undef AF_OWN
+}
+
+// DIST: prefetch distance of this instantiation (default kDist); WPE: waves per SIMD = workgroups per CU.  WPE = 2 (r3) is for the
+// narrow layers whose whole register need fits 256: with DIST = 1 the ring is 3 slots (74 KB per workgroup), two workgroups share
+// a CU and one's epilogue / barriers / waits run under the other's MFMAs.
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST = kDist, int WPE = 1>
+__global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void af_conv_f16s(F16sArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16s_body<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE, 4 / PS, -1>(A, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// 15x15, the layers whose waves hold all four pixel tiles of a pseudo-position (PS = 1: 71 % of that forward): 225 pixels are seven
+// tiles and ONE pixel, and with two 4-tile halves the second half's fourth tile multiplies 31 zero columns out of 32 (88 % tile
+// efficiency).  Here the first A.gx0 workgroups of the launch take half 0 of every board with 4 tiles and the rest
+// take half 1 with 3 (gx0 : gx1 = 9 : 7 ~ 4 : 3, both multiples of 8 so that every XCD gets its share of each class and the
+// XCD-contiguous position map holds inside a class); the corner pixel is computed by af_corner_f16s, batched over 32 boards.
+template <class G, int NSM, int NSP, int CT, int KS, bool XACC>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_conv_f16s_h15(F16sArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gx0 = A.gx0;
+    if ((int)blockIdx.x < gx0) f16s_body<G, NSM, NSP, CT, KS, 1, false, XACC, 0, 0, kDist, 1, 4, 0>(A, smem, (int)blockIdx.x, gx0);
+    else f16s_body<G, NSM, NSP, CT, KS, 1, false, XACC, 0, 0, kDist, 1, 3, 1>(A, smem, (int)blockIdx.x - gx0, (int)gridDim.x - gx0);
+}
+
+// Pixel 224 (the corner (14, 14)) of a 15x15 board for the layers that run af_conv_f16s_h15: one MFMA pixel tile = the corner pixels
+// of 32 BOARDS.  Of the 3x3 taps only (0,0), (0,1), (1,0), (1,1) lie on the board (pixels 208, 209, 223, 224); a lane's B fragment is
+// one 16-byte unit of ITS board, read from the compact copy the half-1 workgroups of af_conv_f16s_h15 made while the slab was in LDS
+// (512 contiguous bytes per slab and board: 9 MB per layer and 4096 boards, L2 / Infinity-Cache resident; straight from the S32 tensor
+// the same units cost three 128-byte lines per 64 useful bytes = 50 MB and 25-45 us per launch: profiles/r5_09); the A fragments are
+// the layer's own packed weights (pack_layer: [cout tile][ks][item][hi|lo]).
+// A workgroup = 32 boards x up to 4 cout tiles (one per wave).
+// BIT-IDENTICAL to what the two-halves launch (af_conv_f16s on half 1, tile 3, lane 0) computes for this pixel — small batches still
+// take that launch, and a board's result must not depend on the batch it is evaluated in: the same MFMAs on the same operands in the
+// same order per accumulator (slabs in stream order, k-step, tap; hi x hi, hi x lo, lo x hi; XACC: cross terms in their own accumulator,
+// added at the end; KS = 2: one accumulator per k-half, summed like the exchange does), minus the MFMAs whose B column is all zero
+// for this pixel (taps off the board: they add +0), and the same epilogue expression.
+struct CornerArgs {
+    const char* stash;    // the corner's operands: [board][slab][hi|lo][4 unit rows][4 pixels] units (written by af_conv_f16s_h15)
+    const uint4* w;       // the layer's packed A fragments
+    const float* bias;
+    char* out;            // S32, NCT slabs per board
+    float inv_scale;
+    int batch, NCT;
+};
+template <class G, int KS, bool XACC, int NSM, int NSP>
+__global__ __launch_bounds__(256) void af_corner_f16s(CornerArgs A) {
+    using L = Lay<G>;
+    constexpr int CPIX = G::NPIX - 1;                                          // 224
+    constexpr int C16 = 2 / KS, NIT = NSP * C16 + NSM * 9 * C16;
+    constexpr int NST = NSM * 8 + NSP * 2;                                     // steps (k-step x on-board tap): three MFMAs each
+    constexpr int D = NST < 12 ? NST : 12;                                     // operand ring: the loads of step t + D are issued behind step t
+    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
+    const int tile = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    if (tile >= A.NCT) return;
+    const int p = 32 * (int)blockIdx.x + nn;
+    const bool valid = p < A.batch;
+    const size_t pc = (size_t)(valid ? p : A.batch - 1);
+    f32x16 acc[KS], acx[XACC ? KS : 1];
+#pragma unroll
+    for (int h = 0; h < KS; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[h][r] = 0.0f; if (XACC) acx[h][r] = 0.0f; }
+    static_assert(AF_F16S_MAIN_FIRST, "the corner kernel restates the main kernel's slab order: 3x3 slabs, then the projection's");
+    // step t -> (k-half, A fragment, B unit): the main kernel's order (slab, k-step, tap; the projection's slabs last)
+    const uint4* const wbase = A.w + (size_t)tile * KS * NIT * 2 * 64 + lane;
+    // B operands: the compact copy the half-1 workgroups of af_conv_f16s_h15 made while the slabs were in LDS:
+    // [board][slab of the stream][hi|lo][unit row][pixel 208, 209, 223, 224] x 16 bytes
+    constexpr int SPP = NSM + NSP;
+    const char* const st0 = A.stash + (pc * SPP * 32 + (uint32_t)kg * 4u) * 16;
+    struct Ops { uint4 a0, a1, b0, b1; };
+    auto half_of = [](int t) constexpr -> int {
+        const int k16 = t < NSM * 8 ? (t >> 2) & 1 : (t - NSM * 8) & 1;
+        return KS == 2 ? k16 : 0;
+    };
+    auto fetch = [&](int t) -> Ops {
+        int k16, item;
+        const char* bsrc;
+        if (t < NSM * 8) {
+            const int s_ = t >> 3, tq = t & 3, ky = tq >> 1, kx = tq & 1;
+            k16 = (t >> 2) & 1;
+            item = NSP * C16 + s_ * 9 * C16 + (KS == 2 ? 0 : k16) * 9 + 3 * ky + kx;
+            bsrc = st0 + (uint32_t)((s_ * 32 + 2 * k16 * 4 + tq) * 16);
+        } else {
+            const int u = t - NSM * 8, s_ = u >> 1;
+            k16 = u & 1;
+            item = s_ * C16 + (KS == 2 ? 0 : k16);
+            bsrc = st0 + (uint32_t)(((NSM + s_) * 32 + 2 * k16 * 4 + 3) * 16);
+        }
+        const uint4* wp = wbase + ((size_t)((KS == 2 ? k16 : 0) * NIT + item) * 2) * 64;
+        Ops o;
+        o.a0 = wp[0]; o.a1 = wp[64];
+        o.b0 = *reinterpret_cast<const uint4*>(bsrc); o.b1 = *reinterpret_cast<const uint4*>(bsrc + 256);
+        return o;
+    };
+    Ops ring[D];
+#pragma unroll
+    for (int t = 0; t < D; ++t) ring[t] = fetch(t);
+    __builtin_amdgcn_sched_barrier(0);                                         // all D steps' loads in flight before the first MFMA
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+        const Ops o = ring[t % D];
+        if (t + D < NST) ring[t % D] = fetch(t + D);
+        const int h = half_of(t);
+        h8 wh, wl, bh, bl;
+        __builtin_memcpy(&wh, &o.a0, 16); __builtin_memcpy(&wl, &o.a1, 16); __builtin_memcpy(&bh, &o.b0, 16); __builtin_memcpy(&bl, &o.b1, 16);
+        acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc[h], 0, 0, 0);
+        if (XACC) {
+            acx[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acx[h], 0, 0, 0);
+            acx[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, acx[h], 0, 0, 0);
+        } else {
+            acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc[h], 0, 0, 0);
+            acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, acc[h], 0, 0, 0);
+        }
+        // keep the ring a ring: hipcc otherwise sinks every load to its use (54 registers, one memory round trip per step)
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                     // 3 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                     // 4 VMEM reads (step t + D)
+    }
+    if (XACC) {
+#pragma unroll
+        for (int h = 0; h < KS; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][r] += acx[h][r];
+    }
+    if (KS == 2) {                                                             // the exchange: the finishing wave adds its partner's partial sum
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[KS - 1][r] + acc[0][r];
+    }
+    if (!valid) return;
+    // epilogue as in the main kernel: a lane's 16 accumulator rows are the couts 32 tile + 16 kg + r
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 pre = f32x2{acc[0][r], acc[0][r + 1]} * A.inv_scale + f32x2{A.bias[32 * tile + 16 * kg + r], A.bias[32 * tile + 16 * kg + r + 1]};
+        const f32x2 y = elu2(pre);
+        v[r] = y.x; v[r + 1] = y.y;
+    }
+    char* o = A.out + ((size_t)p * A.NCT + tile) * L::kSlabH + (uint32_t)(2 * kg) * L::kRowH + (uint32_t)(CPIX + G::POFF) * 16u;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = v[8 * hf + e];
+            const _Float16 h = (_Float16)f;
+            hi[e] = h;
+            lo[e] = (_Float16)(f - (float)h);
+        }
+        st16(o + hf * L::kRowH, hi);
+        st16(o + hf * L::kRowH + L::kHalfH, lo);
+    }
 }
 
 // 5x5 stem (3 -> 32, SAME) + bias + ELU (network.py:63) on the VALU (2,400 MAC per pixel), output split into S32 — any board
@@ -1274,6 +1443,42 @@ int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     return 0;
 }
 
+// 15x15, PS = 1 layers: the two half classes in one launch (af_conv_f16s_h15) + the corner pixel (af_corner_f16s) behind it
+template <class G, int NSM, int NSP, int CT, int KS, bool XACC>
+int launch_h15(hipStream_t st, F16sArgs a, int gy, int ncu) {
+    constexpr size_t lds = Lds<G, kDist>::kScrOff + (KS == 2 ? (size_t)CT * 4 * 4096 : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    FS_HIP_OK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s_h15<G, NSM, NSP, CT, KS, XACC>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_devs.fetch_or(bit, std::memory_order_relaxed);
+    }
+    // gx workgroups per blockIdx.y, split 9 : 7 between the 4-tile class (half 0) and the 3-tile class (half 1), each a multiple of 8
+    // (4 x 28.4 = 114 against 3 x 36.6 = 110 tile passes per workgroup at 4096 boards on 144 + 112 workgroups)
+    const int gx = std::max(16, ncu / gy / 16 * 16);
+    // class sizes: KS = 1 (every wave finishes all its tiles: a workgroup's time scales with its tile count) 9 : 7; KS = 2 (the k-split
+    // exchange, the finishing wave's two epilogues and the slab stream do not shrink with the third tile: a half-1 workgroup's board costs
+    // ~0.86 of a half-0 one, profiles/r5_10) 17 : 15.  A/B knobs: AF_F16S_H15_NUM1 / _NUM2 = gx0 * 32 / gx, AF_F16S_H15_ROUND = 1 rounds to 8.
+    static const int num1 = [] { const char* e = getenv("AF_F16S_H15_NUM1"); const int v = e ? atoi(e) : 0; return v > 0 && v < 32 ? v : 18; }();
+    static const int num2 = [] { const char* e = getenv("AF_F16S_H15_NUM2"); const int v = e ? atoi(e) : 0; return v > 0 && v < 32 ? v : 17; }();
+    static const int rnd = [] { const char* e = getenv("AF_F16S_H15_ROUND"); return e ? atoi(e) : 1; }();
+    const int num = KS == 1 ? num1 : num2;
+    a.gx0 = rnd ? std::max(8, (gx * num / 32 + 4) / 8 * 8) : std::max(1, gx * num / 32);
+    if (a.gx0 >= gx) a.gx0 = gx - 8;
+    hipLaunchKernelGGL((af_conv_f16s_h15<G, NSM, NSP, CT, KS, XACC>), dim3(gx, gy), dim3(256), lds, st, a);
+    FS_HIP_OK(hipGetLastError());
+    CornerArgs c;
+    c.stash = a.stash; c.w = a.w; c.bias = a.bias; c.out = a.out; c.inv_scale = a.inv_scale;
+    c.batch = a.batch; c.NCT = gy * CT;
+    hipLaunchKernelGGL((af_corner_f16s<G, KS, XACC, NSM, NSP>), dim3((a.batch + 31) / 32, (c.NCT + 3) / 4), dim3(256), 0, st, c);
+    FS_HIP_OK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 struct f16s_net {
@@ -1295,6 +1500,7 @@ struct f16s_net {
     float *hcb[2] = {}, *hfb[2] = {}, *v2w = nullptr, *v2b = nullptr;
     float hc_inv[2] = {}, hf_inv[2] = {};
     char* hx[2] = {};
+    char* stash = nullptr;        // 15x15: corner operands of the layer in flight (af_conv_f16s_h15 -> af_corner_f16s), 6 slabs x 512 B per board
     int abl = 0;
 };
 
@@ -1365,6 +1571,12 @@ int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const
         *p = (char*)q;
         return 0;
     };
+    if (!rc && !s11) {
+        void* q = nullptr;
+        FS_HIP_OK(hipMalloc(&q, (size_t)max_batch * 6 * 512));
+        n->allocs.push_back(q);
+        n->stash = (char*)q;
+    }
     if (!rc) rc = act(&n->f0, 32);
     for (int b = 0; b < 5 && !rc; ++b) {
         rc = act(&n->g[b], kLayers[2 * b].cout);
@@ -1445,15 +1657,25 @@ static int launch_layer_g(f16s_net* n, hipStream_t st, int li, const F16sArgs& a
             if constexpr (G::S == 11) { if (!(n->abl & 32)) return launch_cfg<G, 1, 0, 2, 1, 2, false, false, 0, 0, 1, 2>(st, a, 1, n->ncu); }   // (no XACC: 256 registers)
             return launch_cfg<G, 1, 0, 2, 1, 2, false, true>(st, a, 1, n->ncu);
         case 1: return launch_cfg<G, 2, 1, 2, 1, 2, false, true>(st, a, 1, n->ncu);
-        case 2: return launch_cfg<G, 2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
-        case 3: return launch_cfg<G, 4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
+        // 15x15 (r5): the four PS = 1 layers run the 4-tile / 3-tile half classes + the corner kernel (abl bit 6 = the r3 two-halves launch,
+        // for A/B; small batches keep it too: the class split assumes every workgroup has boards of its half)
+        case 2:
+            if constexpr (G::S == 15) { if (!(n->abl & 64) && a.batch >= 128) return launch_h15<G, 2, 0, 4, 1, false>(st, a, 1, n->ncu); }
+            return launch_cfg<G, 2, 0, 4, 1, 1, false, false>(st, a, 1, n->ncu);   // (as 2 workgroup kinds x (2 tiles, k-split, XACC): 1.605 vs 1.580 ms per forward, |dp| 1.23e-5 vs 1.28e-5)
+        case 3:
+            if constexpr (G::S == 15) { if (!(n->abl & 64) && a.batch >= 128) return launch_h15<G, 4, 2, 2, 2, false>(st, a, 2, n->ncu); }
+            return launch_cfg<G, 4, 2, 2, 2, 1, false, false>(st, a, 2, n->ncu);
         case 4: return launch_cfg<G, 4, 0, 1, 2, 2, false, false, 1>(st, a, 1, n->ncu);   // (no XACC: weights + projection weights + 3 accumulator sets would spill)
         case 5:                                                                           // (one pixel tile per wave, whole K: no k-split exchange)
             if constexpr (G::S == 11) { if (head == 0 && !(n->abl & 32)) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 1, 1, 2>(st, a, 1, n->ncu); }
             if (head == 0) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 1>(st, a, 1, n->ncu);
             return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2>(st, a, 1, n->ncu);
-        case 6: return launch_cfg<G, 4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
-        case 7: return launch_cfg<G, 2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
+        case 6:
+            if constexpr (G::S == 15) { if (!(n->abl & 64) && a.batch >= 128) return launch_h15<G, 4, 0, 2, 2, false>(st, a, 1, n->ncu); }
+            return launch_cfg<G, 4, 0, 2, 2, 1, false, false>(st, a, 1, n->ncu);
+        case 7:
+            if constexpr (G::S == 15) { if (!(n->abl & 64) && a.batch >= 128) return launch_h15<G, 2, 4, 2, 2, true>(st, a, 1, n->ncu); }
+            return launch_cfg<G, 2, 4, 2, 2, 1, false, true>(st, a, 1, n->ncu);
         case 8: return launch_cfg<G, 2, 0, 1, 1, 4, false, true, 1>(st, a, 1, n->ncu);
         default:
             if constexpr (G::S == 11) { if (head == 1 && !(n->abl & 32)) return launch_cfg<G, 1, 0, 1, 1, 4, true, true, 2, 2, 1, 2>(st, a, 1, n->ncu); }
@@ -1468,7 +1690,7 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
     a.hw = nullptr; a.hbias = nullptr; a.hx = nullptr; a.inv_scale_h = 1.0f;
     if (head >= 0) { a.hw = n->hcw[head]; a.hbias = n->hcb[head]; a.hx = n->hx[head]; a.inv_scale_h = n->hc_inv[head]; }
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
-    a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xff) | (li << 8);
+    a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xff) | (li << 8); a.gx0 = 0; a.stash = n->stash;
     a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
     return n->S == 11 ? launch_layer_g<Geo<11>>(n, st, li, a, head) : launch_layer_g<Geo<15>>(n, st, li, a, head);
 }
