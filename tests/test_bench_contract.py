@@ -10,7 +10,7 @@ from conftest import REPO
 
 
 def _last_line():
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r4_*_bench_driver_command.json")))
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r5_*_bench_driver_command.json")))
     assert files, "no committed bench line of this round"
     with open(files[-1]) as f:
         lines = [ln for ln in f if ln.startswith("{")]
