@@ -254,13 +254,15 @@ struct F16sArgs {
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
 };
 
-// The kernel body.  NTW: pixel tiles per wave (4 / PS for a whole pseudo-position).  HSEL (r5, 15x15 only): -1 = the workgroups of
+// The kernel body.  NTW: pixel tiles per wave (4 / PS for a whole pseudo-position); tb: the first pixel tile of this workgroup
+// (af_conv_f16s_sb, r5: at small batches a pseudo-position's tiles are split over several workgroups — a tile's accumulation does not
+// depend on which workgroup runs it, so the results are the batched kernel's bit for bit).  HSEL (r5, 15x15 only): -1 = the workgroups of
 // this launch take both halves of the boards alternately (bx even / odd, the r3 scheme); 0 / 1 = the `gxw` workgroups of this CLASS
 // (index bx) take that half of EVERY board — af_conv_f16s_h15 runs a class of NTW = 4 workgroups on half 0 (pixels 0..127) next to
 // a class of NTW = 3 workgroups on half 1 (pixels 128..223: three full tiles; pixel 224, the fourth tile's only pixel, is left to
 // af_corner_f16s) in one launch.
 template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST, int WPE, int NTW, int HSEL>
-__device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const int bx, const int gxw) {
+__device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const int bx, const int gxw, const int tb = 0) {
     using L = Lay<G>;
     constexpr uint32_t kRowH = L::kRowH, kHalfH = L::kHalfH, kSlabH = L::kSlabH, kRowL = L::kRowL, kHalfL = L::kHalfL, kSlotL = L::kSlotL;
     constexpr uint32_t kZoff = Lds<G, DIST>::kZoff, kBiasOff = Lds<G, DIST>::kBiasOff, kScrOff = Lds<G, DIST>::kScrOff;
@@ -396,7 +398,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     bool ok[NT], edgeL[NT], edgeR[NT];
 #pragma unroll
     for (int jj = 0; jj < NT; ++jj) {
-        const int n = 128 * hv + 32 * (ps * NT + ((jj + rot) % NT)) + nn;
+        const int n = 128 * hv + 32 * (tb + ps * NT + ((jj + rot) % NT)) + nn;
         ok[jj] = n < G::NPIX;
         const int nc = ok[jj] ? n : 128 * hv;                                // (an invalid lane works on the half's first pixel)
         pix[jj] = nc;
@@ -479,7 +481,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
         if (PJ == 2) {
 #pragma unroll
             for (int jf = 0; jf < NFIN; ++jf) {
-                const int tile = ps * NT + (KS == 2 ? ks * NFIN : 0) + jf;
+                const int tile = tb + ps * NT + (KS == 2 ? ks * NFIN : 0) + jf;
                 const f32x4* src = reinterpret_cast<const f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + tile) * 4) * 64 + lane;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) padd[jf][q] = src[q * 64];
@@ -651,7 +653,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
                 if (!AF_OWN(jj)) continue;
-                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + ps * NT + ((jj + rot) % NT)) * 4) * 64 + lane;
+                f32x4* dst = reinterpret_cast<f32x4*>(A.pbuf) + ((((size_t)qpos * nso + ctg) * 4 + tb + ps * NT + ((jj + rot) % NT)) * 4) * 64 + lane;
                 if (!(A.abl & 2)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -780,6 +782,16 @@ template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XA
 __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void af_conv_f16s(F16sArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16s_body<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE, 4 / PS, -1>(A, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Small batches (r5; the drop-in Player evaluates ONE leaf per simulation): with <= 8 positions a launch is one workgroup per position
+// that works through all four pixel tiles — 14-16 k cycles of MFMAs in the wide layers next to an 8 k-cycle start-up
+// (profiles/r5_14_f16s_phases_batch1.txt).  Here gridDim.z workgroups share a pseudo-position, NTW tiles per wave each (1 where every
+// wave holds its whole K, 2 under a k-split: each wave of a pair finishes one).  Per tile the same MFMAs in the same order: bit-identical.
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST, int WPE, int NTW>
+__global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void af_conv_f16s_sb(F16sArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16s_body<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE, NTW, -1>(A, smem, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z * PS * NTW);
 }
 
 // 15x15, the layers whose waves hold all four pixel tiles of a pseudo-position (PS = 1: 71 % of that forward): 225 pixels are seven
@@ -1416,6 +1428,7 @@ std::vector<_Float16> pack_frags(int nfrag, F&& val) {          // [fragment][hi
     return out;
 }
 
+constexpr int kSmallBatch = 8;             // <= this many positions: a position's pixel tiles are split over workgroups (af_conv_f16s_sb)
 template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ = 0, int HD = 0, int DIST = kDist, int WPE = 1>
 int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     constexpr int NT = 4 / PS;
@@ -1434,6 +1447,21 @@ int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
         FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_devs.fetch_or(bit, std::memory_order_relaxed);
+    }
+    constexpr int NTS = KS == 2 ? 2 : 1;                                  // tiles per wave of the small-batch split
+    if constexpr (NTS < NT && HD == 0) {
+        if (a.batch <= kSmallBatch && !(a.abl & 128)) {                    // (abl bit 7: the one-workgroup-per-position launch, for A/B)
+            static std::atomic<uint64_t> attr_sb{0};
+            if (!(attr_sb.load(std::memory_order_relaxed) & bit)) {
+                FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_f16s_sb<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE, NTS>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_sb.fetch_or(bit, std::memory_order_relaxed);
+            }
+            hipLaunchKernelGGL((af_conv_f16s_sb<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE, NTS>),
+                               dim3(a.batch * G::HALVES, gy, NT / NTS), dim3(256), lds, st, a);
+            FS_HIP_OK(hipGetLastError());
+            return 0;
+        }
     }
     // one workgroup per CU, a multiple of HALVES of them (a workgroup keeps one half of the board for the whole launch)
     int gx = std::max(1, std::min(a.batch * G::HALVES, WPE * ncu / gy));

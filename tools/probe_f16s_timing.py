@@ -17,7 +17,7 @@ from test_gpu_net import _positions
 
 net = ResNet(11, device="cuda")
 net.load_npz(os.path.join(REPO, "tests", "golden", "alphaFive-6960.weights.npz"))
-B = 4096
+B = int(os.environ.get("B", 4096))
 hn = net_hip.HipNet(net.variables, 11, B, "cuda")
 xb = torch.from_numpy(_positions(11, B, seed=1)).cuda()
 net_hip.tune(0, 5)
@@ -46,3 +46,4 @@ for li in range(10):
         d[:, q].sum() / d[:, 6].sum() for q in (0, 1, 2, 3, 4)))
     print("      per wave: items %s  epilogue %s  exch-barrier %s (cycles per position)" % tuple(
         np.round(w[:, :, q].sum(0) / w[:, :, 6].sum(0)).astype(int).tolist() for q in (0, 4, 7)))
+    print("      start-up (kernel entry -> weights and first slabs in place): %.0f cycles" % (w[:, :, 8].mean()))
