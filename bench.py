@@ -345,6 +345,10 @@ def spawn_ranks(n, timeout_s=None):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AF_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+    def _stop(signum, frame):                     # the launcher being stopped (a driver's timeout) must not leave ranks behind
+        raise KeyboardInterrupt
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, _stop)
     rc, t0 = 0, time.time()
     try:
         live = list(procs)
@@ -619,7 +623,8 @@ def main():
     ones = torch.ones(1, device=comm_dev, dtype=torch.float64)
     props = torch.cuda.get_device_properties(dev)
     me = {"rank": rank, "device": "cuda:%d" % local, "name": props.name,
-          "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "uuid": str(getattr(props, "uuid", "")),
+          "pci_bus_id": "%s:%s:%s" % (getattr(props, "pci_domain_id", "?"), getattr(props, "pci_bus_id", "?"), getattr(props, "pci_device_id", "?")),
           "episodes_finished": int(ct1["episodes"] - ct0["episodes"]), "plies": int(plies), "elapsed_s": elapsed}
     ranks_info = [me]
     if world > 1:
@@ -732,8 +737,8 @@ def main():
                        "ranks_seen": ranks_seen, "backend": backend if world > 1 else "none (single process)",
                        "launcher": "bench.py spawn_ranks" if os.environ.get("AF_BENCH_SPAWNED") == "1" else
                                    ("torch.distributed.run / external" if world > 1 else "single process"),
-                       "devices": ["%s %s %s" % (r["device"], r["name"], r["pci_bus_id"] or r["uuid"]) for r in ranks_info],
-                       "distinct_devices": len({(r["pci_bus_id"] or r["uuid"] or r["device"]) for r in ranks_info}),
+                       "devices": ["%s %s pci %s uuid %s" % (r["device"], r["name"], r["pci_bus_id"], r["uuid"][:13]) for r in ranks_info],
+                       "distinct_devices": len({(r["uuid"] or r["pci_bus_id"]) for r in ranks_info}),
                        "per_rank": [{"rank": r["rank"], "episodes_finished": r["episodes_finished"], "plies": r["plies"],
                                      "elapsed_s": r["elapsed_s"]} for r in ranks_info],
                        "episodes_gathered_total": gathered_total, "episodes_finished_total_all_ranks": finished_total,
