@@ -249,6 +249,9 @@ struct F16sArgs {
     char* hx;             // value: [position][hi|lo][128 pixels][4] fp16; policy: [position][hi|lo][128 pixels][16] fp16
     float inv_scale_h;
     int batch, WP, PP;
+    const uint4* w2;      // fused block (FU): the second convolution's packed A fragments (36,864 bytes), its bias [32] and 1 / weight scale
+    const float* bias2;
+    float inv_scale2;
     int gx0;              // af_conv_f16s_h15: workgroups (per blockIdx.y) of the half-0 class
     char* stash;          // af_conv_f16s_h15 -> af_corner_f16s: [board][slab of the stream][hi|lo][4 unit rows][pixels 208, 209, 223, 224] units
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
@@ -261,13 +264,29 @@ struct F16sArgs {
 // (index bx) take that half of EVERY board — af_conv_f16s_h15 runs a class of NTW = 4 workgroups on half 0 (pixels 0..127) next to
 // a class of NTW = 3 workgroups on half 1 (pixels 128..223: three full tiles; pixel 224, the fourth tile's only pixel, is left to
 // af_corner_f16s) in one launch.
-template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST, int WPE, int NTW, int HSEL>
+// FU (r5): 1 / 2 = the block's SECOND convolution (32 -> 32, the value / policy branch's last one, with the fused head) runs in this kernel
+// too, on the first one's output kept in LDS — see "fused block" below.
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST, int WPE, int NTW, int HSEL, int FU = 0>
 __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const int bx, const int gxw, const int tb = 0) {
     using L = Lay<G>;
     constexpr uint32_t kRowH = L::kRowH, kHalfH = L::kHalfH, kSlabH = L::kSlabH, kRowL = L::kRowL, kHalfL = L::kHalfL, kSlotL = L::kSlotL;
     constexpr uint32_t kZoff = Lds<G, DIST>::kZoff, kBiasOff = Lds<G, DIST>::kBiasOff, kScrOff = Lds<G, DIST>::kScrOff;
     constexpr int kDist = DIST, kRing = DIST + 2;                             // (shadow the file-level default)
     constexpr int NPC = G::NPC, HV = G::HALVES;
+    // Fused block (FU > 0; blocks 3 and 5 of the 11x11 net: 128 -> 32 -> 32 and 64 -> 32 -> 32).  Unfused, the first convolution
+    // writes its 32 channels (15 KB, split) and the block's projection (16 KB, fp32) to HBM and the second one reads both back: 64 KB
+    // of a block's 103 / 129 KB per position, on layers that run at 4-5 TB/s (profiles/r5_01: HBM-bound).  Fused: every wave ends
+    // the first convolution owning ONE pixel tile (PS = 4, or the k-split's finished tile; tile index = wave index in both
+    // convolutions), writes its activated tile into an LDS slab in ring-slot layout, keeps the projection's accumulators in
+    // registers, and after a barrier runs the second convolution on that slab: B fragments exactly like ring-slot reads, A fragments
+    // from a copy of the second layer's 36 KB of packed weights in LDS (320 + 160 weight registers do not fit a wave) — the same
+    // MFMAs on the same operands in the same order as af_conv_f16s<G,1,0,1,1,4,true,true,2,HD> runs them, then its epilogue and the
+    // fused head: bit-identical outputs (the digest of 4096 positions equals the unfused build's).
+    static_assert(FU == 0 || (G::HALVES == 1 && PJ == 1 && HD == 0 && !OUT32 && NSP == 0 && CT == 1 && HSEL < 0 &&
+                              ((KS == 1 && NTW == 1) || (KS == 2 && NTW == 2))), "fused block: see above");
+    constexpr uint32_t kScrBytes = KS == 2 ? (uint32_t)(CT * PS * NTW) * 4096u * (PJ == 1 ? 2u : 1u) : 0u;
+    constexpr uint32_t kGOff = Lds<G, DIST>::kScrOff;                         // KS = 2: inside the exchange scratch (pads re-zeroed per position)
+    constexpr uint32_t kW2Off = kGOff + (kScrBytes > Lay<G>::kSlotL ? kScrBytes : Lay<G>::kSlotL);
     constexpr int NT = NTW;                       // pixel tiles per wave
     static_assert(HSEL < 0 || (HV == 2 && PJ == 0 && HD == 0 && !OUT32), "half classes: plain 15x15 layers only");
     static_assert(NT % KS == 0 || PJ == 0, "an odd tile count under a k-split has no projection exchange");
@@ -371,9 +390,20 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
             __builtin_memcpy(&PW[f], &v, 16);
         }
     }
-    h8 HA[HD > 0 ? 4 : 1];
-    float hb[HD > 0 ? 8 : 1];
-    if (HD > 0) {
+    constexpr int HDS = HD > 0 ? HD : FU;         // which head's 1x1 convolution this kernel applies (0: none)
+    h8 HA[HDS > 0 ? 4 : 1];
+    float hb[HDS > 0 ? 8 : 1];
+    if (FU > 0) {
+        // the second convolution's A fragments -> LDS ([item][hi|lo][64 lanes] x 16 bytes, pack_layer's order), its bias -> registers
+        const uint4* w2 = A.w2;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) *reinterpret_cast<uint4*>(smem + kW2Off + (uint32_t)(i * 256 + (int)threadIdx.x) * 16u) = w2[i * 256 + threadIdx.x];
+        if (threadIdx.x < 32) reinterpret_cast<float*>(smem + kBiasOff + 256u)[threadIdx.x] = A.bias2[threadIdx.x];      // (the first layer's 32 biases sit at + 0)
+        if (KS == 1) {      // the activation slab's pad units: zeroed once (KS = 2: the slab lives in the exchange scratch, see the position loop)
+            for (uint32_t u = threadIdx.x; u < kSlotL / 16; u += 256) *reinterpret_cast<uint4*>(smem + kGOff + u * 16) = uint4{0, 0, 0, 0};
+        }
+    }
+    if (HDS > 0) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const uint4 v = A.hw[f * 64 + lane];
@@ -414,7 +444,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     // directly: with "+v" for all of them hipcc parked the surplus there anyway and copied every fragment back with four
     // v_accvgpr_read before use (0.7-2 VALU instructions per MFMA in the item loop of the wide layers; r3_38).
     constexpr int kAccRegs = 16 * NT * (1 + (XACC ? 1 : 0) + (PJ == 1 ? 1 : 0));
-    constexpr int kWRegs = 4 * (2 * NIT + (PJ == 1 ? 2 * NPW : 0) + (HD > 0 ? 4 : 0));
+    constexpr int kWRegs = 4 * (2 * NIT + (PJ == 1 ? 2 * NPW : 0) + (HDS > 0 ? 4 : 0));
     constexpr int kNAmax = (256 - kAccRegs - 16) / 4, kNAwant = (kWRegs - AF_F16S_VW + 3) / 4;
     constexpr int NA = (AF_F16S_APIN && WPE == 1 && kNAwant > 0) ? (kNAwant < kNAmax ? kNAwant : kNAmax) : 0;
 #pragma unroll
@@ -426,7 +456,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
 #pragma unroll
         for (int f = 0; f < 2 * NPW; ++f) asm volatile("" : "+v"(PW[f]));
     }
-    if (HD > 0) {
+    if (HDS > 0) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(HA[f]));
     }
@@ -443,6 +473,56 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
         return *reinterpret_cast<const h8*>(sm + base + imm);
     };
 
+    // the head's 1x1 convolution on a finished tile (the last convolution of a branch, or the fused block's second one)
+    auto head_tile = [&](const float (&v)[16], const int jj, const int pos) {
+      if constexpr (HDS > 0) {
+                // a lane holds channels 16 kg + r of its pixel: r = 0..7 and r = 8..15 are the B fragments of two k-steps whose k
+        // index 8 kgrp + e stands for channel 16 kgrp + 8 step + e (the A fragments are packed to match)
+        h8 bh[2], bl[2];
+#pragma unroll
+        for (int st_ = 0; st_ < 2; ++st_)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = v[8 * st_ + e];
+                const _Float16 h = (_Float16)f;
+                bh[st_][e] = h;
+                bl[st_][e] = (_Float16)(f - (float)h);
+            }
+        f32x16 a2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[r] = 0.0f;
+#pragma unroll
+        for (int st_ = 0; st_ < 2; ++st_) {
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_], bh[st_], a2, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_], bl[st_], a2, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_ + 1], bh[st_], a2, 0, 0, 0);
+        }
+        // accumulator rows 0..7 of a lane = head channels 8 kg + r
+        constexpr int NR = HDS == 1 ? 4 : 8;
+        _Float16 uh[8], ul[8];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float f = elu1(a2[r] * A.inv_scale_h + hb[r]);
+            const _Float16 h = (_Float16)f;
+            uh[r] = h;
+            ul[r] = (_Float16)(f - (float)h);
+        }
+        if (ok[jj] && !(A.abl & 2)) {
+            if (HDS == 1) {
+                if (kg == 0) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    char* o = A.hx + (size_t)pos * Hx<G>::kValPos + (uint32_t)pix[jj] * 8u;
+                    *reinterpret_cast<h4*>(o) = h4{uh[0], uh[1], uh[2], uh[3]};
+                    *reinterpret_cast<h4*>(o + Hx<G>::kValLo) = h4{ul[0], ul[1], ul[2], ul[3]};
+                }
+            } else {
+                char* o = A.hx + (size_t)pos * Hx<G>::kPolPos + (uint32_t)pix[jj] * 32u + (uint32_t)kg * 16u;
+                *reinterpret_cast<h8*>(o) = h8{uh[0], uh[1], uh[2], uh[3], uh[4], uh[5], uh[6], uh[7]};
+                *reinterpret_cast<h8*>(o + Hx<G>::kPolLo) = h8{ul[0], ul[1], ul[2], ul[3], ul[4], ul[5], ul[6], ul[7]};
+            }
+        }
+      }
+    };
     uint32_t t = 0;
     uint32_t cur = 0u, nxd = (uint32_t)kDist * kSlotL;        // ring slots of slab t and of slab t + kDist
     // Fragments are double buffered per item and prefetched one item ahead ACROSS slab (and position) boundaries: the
@@ -451,7 +531,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     // the one of slab t-2, which every wave left before the barrier inside slab t-1.)
     // XPOS: the prefetch also crosses the position boundary (the fragments stay live through the epilogue) — not where
     // weights + accumulators already fill the register file (4 pixel tiles and >= 288 weight registers)
-    constexpr bool XPOS = !(NT >= 3 && NIT >= 36);
+    constexpr bool XPOS = !(NT >= 3 && NIT >= 36) && FU == 0;      // (fused block: the second convolution needs the registers)
     h8 fr[2][NT][2];
 #define AF_FIRST_ITEM(slot)                                                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                          \
@@ -649,7 +729,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
         }
 #undef AF_EXCHANGE
 #undef AF_COMBINE
-        if (PJ == 1) {                                                       // the projection, fp32, in accumulator layout
+        if (PJ == 1 && FU == 0) {                                            // the projection, fp32, in accumulator layout
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj) {
                 if (!AF_OWN(jj)) continue;
@@ -664,6 +744,16 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
             }
         }
 
+        if (FU > 0 && KS == 2) {
+            // the activation slab aliases the exchange scratch: every wave must have read its partner's partial sums before anyone
+            // writes activations there, and the slab's pad units (a window's units left and right of the board) are zero again
+            __builtin_amdgcn_s_barrier();
+            for (uint32_t u = threadIdx.x; u < 8u * (G::WINU - (uint32_t)G::NPIX); u += 256) {
+                const uint32_t row = u / (G::WINU - (uint32_t)G::NPIX), k = u % (G::WINU - (uint32_t)G::NPIX);
+                const uint32_t unit = k < (uint32_t)G::POFF ? k : k + (uint32_t)G::NPIX;
+                *reinterpret_cast<uint4*>(smem + kGOff + row * kRowL + unit * 16u) = uint4{0, 0, 0, 0};
+            }
+        }
         AF_T(tp2);
         // epilogue: scale back, bias, ELU; split into halves and store (or fp32 planes for the heads).  The weight
         // rows are packed so that a lane's 16 accumulator rows are the couts 32*ctg + 16*kg + r.
@@ -685,51 +775,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
                 v[r] = y.x; v[r + 1] = y.y;
             }
             if (HD > 0) {
-                // a lane holds channels 16 kg + r of its pixel: r = 0..7 and r = 8..15 are the B fragments of two k-steps whose k
-                // index 8 kgrp + e stands for channel 16 kgrp + 8 step + e (the A fragments are packed to match)
-                h8 bh[2], bl[2];
-#pragma unroll
-                for (int st_ = 0; st_ < 2; ++st_)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float f = v[8 * st_ + e];
-                        const _Float16 h = (_Float16)f;
-                        bh[st_][e] = h;
-                        bl[st_][e] = (_Float16)(f - (float)h);
-                    }
-                f32x16 a2;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a2[r] = 0.0f;
-#pragma unroll
-                for (int st_ = 0; st_ < 2; ++st_) {
-                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_], bh[st_], a2, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_], bl[st_], a2, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(HA[2 * st_ + 1], bh[st_], a2, 0, 0, 0);
-                }
-                // accumulator rows 0..7 of a lane = head channels 8 kg + r
-                constexpr int NR = HD == 1 ? 4 : 8;
-                _Float16 uh[8], ul[8];
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const float f = elu1(a2[r] * A.inv_scale_h + hb[r]);
-                    const _Float16 h = (_Float16)f;
-                    uh[r] = h;
-                    ul[r] = (_Float16)(f - (float)h);
-                }
-                if (ok[jj] && !(A.abl & 2)) {
-                    if (HD == 1) {
-                        if (kg == 0) {
-                            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                            char* o = A.hx + (size_t)pos * Hx<G>::kValPos + (uint32_t)pix[jj] * 8u;
-                            *reinterpret_cast<h4*>(o) = h4{uh[0], uh[1], uh[2], uh[3]};
-                            *reinterpret_cast<h4*>(o + Hx<G>::kValLo) = h4{ul[0], ul[1], ul[2], ul[3]};
-                        }
-                    } else {
-                        char* o = A.hx + (size_t)pos * Hx<G>::kPolPos + (uint32_t)pix[jj] * 32u + (uint32_t)kg * 16u;
-                        *reinterpret_cast<h8*>(o) = h8{uh[0], uh[1], uh[2], uh[3], uh[4], uh[5], uh[6], uh[7]};
-                        *reinterpret_cast<h8*>(o + Hx<G>::kPolLo) = h8{ul[0], ul[1], ul[2], ul[3], ul[4], ul[5], ul[6], ul[7]};
-                    }
-                }
+                head_tile(v, jj, pos);
             } else if (OUT32) {
                 const int y = pix[jj] / G::S, x = pix[jj] - y * G::S;
                 float* o = A.out32 + ((size_t)pos * (nso * 32) + 32 * ctg + 16 * kg) * A.PP + (y + 1) * A.WP + x + 1;
@@ -739,6 +785,8 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
                 }
             } else {
                 char* o = A.out + ((size_t)pos * nso + ctg) * kSlabH + (uint32_t)(2 * kg) * kRowH + (uint32_t)(pix[jj] + G::POFF) * 16u;
+                // fused block: the tile goes into the LDS activation slab instead (ring-slot layout: [hi|lo][4 unit rows][WINU units])
+                char* og = smem + kGOff + (uint32_t)(2 * kg) * kRowL + (uint32_t)(pix[jj] + G::POFF) * 16u;
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     h8 hi, lo;
@@ -749,12 +797,68 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
                         hi[e] = h;
                         lo[e] = (_Float16)(f - (float)h);
                     }
-                    if (ok[jj] && !(A.abl & 2)) {             // (tile 3 always has valid lanes: the two stores are always issued)
+                    if (FU > 0) {
+                        if (ok[jj]) {
+                            *reinterpret_cast<h8*>(og + hf * kRowL) = hi;
+                            *reinterpret_cast<h8*>(og + hf * kRowL + kHalfL) = lo;
+                        }
+                    } else if (ok[jj] && !(A.abl & 2)) {      // (tile 3 always has valid lanes: the two stores are always issued)
                         st16(o + hf * kRowH, hi);
                         st16(o + hf * kRowH + kHalfH, lo);
                     }
                 }
             }
+        }
+        if constexpr (FU > 0) {
+            // ---- the block's second convolution (32 -> 32, one slab, K = 2 k-steps x 9 taps) on the slab just written ----
+            // this wave's tile: its slot 0 (tile index = wave index, as in af_conv_f16s<G,1,0,1,1,4,...> where ps = wave)
+            float pj[16];                                     // the block's projection, scaled as the pbuf hand-off scales it
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { pj[r] = pac[0][r] * A.inv_scale_p; asm volatile("" : "+v"(pj[r])); }   // (a product, then a plain add: no fma)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // every wave's tile is in the slab
+            const uint32_t gb = kGOff + (uint32_t)kg * kRowL + (uint32_t)((pix[0] + G::POFF - G::S - 1) * 16);
+            const uint32_t gz = kZoff + (gb & 255u);
+            const uint32_t c2 = (AF_F16S_ZPAD && !ok[0]) ? gz : gb, l2 = edgeL[0] ? gz : c2, r2 = edgeR[0] ? gz : c2;
+            auto rd2 = [&](int it, int p) -> h8 {
+                const int c = it / 9, tap = it % 9, ky = tap / 3, kx = tap % 3;
+                const uint32_t base = kx == 0 ? l2 : (kx == 2 ? r2 : c2);
+                return *reinterpret_cast<const h8*>(smem + base + (uint32_t)p * kHalfL + 2u * c * kRowL + (uint32_t)(ky * G::S + kx) * 16u);
+            };
+            auto wa2 = [&](int it, int hl) -> h8 { return *reinterpret_cast<const h8*>(smem + kW2Off + (uint32_t)((2 * it + hl) * 64 + lane) * 16u); };
+            f32x16 a2, x2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a2[r] = 0.0f; x2[r] = 0.0f; }
+            h8 f2[2][2], w2f[2][2];
+            f2[0][0] = rd2(0, 0); f2[0][1] = rd2(0, 1); w2f[0][0] = wa2(0, 0); w2f[0][1] = wa2(0, 1);
+#pragma clang loop unroll(full)
+            for (int it = 0; it < 18; ++it) {
+                const int b = it & 1;
+                if (it + 1 < 18) {
+                    f2[b ^ 1][0] = rd2(it + 1, 0); f2[b ^ 1][1] = rd2(it + 1, 1);
+                    w2f[b ^ 1][0] = wa2(it + 1, 0); w2f[b ^ 1][1] = wa2(it + 1, 1);
+                }
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[b][0], f2[b][0], a2, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[b][0], f2[b][1], x2, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[b][1], f2[b][0], x2, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_barrier();                     // every wave is done reading the slab (the next position's epilogue / exchange writes it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[r] += x2[r];
+            float v2[16], bs2[16];
+            {
+                const f32x4* bp = reinterpret_cast<const f32x4*>(smem + kBiasOff + 256u + (uint32_t)(16 * kg) * 4u);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const f32x4 v = bp[q]; bs2[4 * q] = v[0]; bs2[4 * q + 1] = v[1]; bs2[4 * q + 2] = v[2]; bs2[4 * q + 3] = v[3]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 pre = f32x2{a2[r], a2[r + 1]} * A.inv_scale2 + f32x2{bs2[r], bs2[r + 1]};
+                pre += f32x2{pj[r], pj[r + 1]};
+                const f32x2 y = elu2(pre);
+                v2[r] = y.x; v2[r + 1] = y.y;
+            }
+            head_tile(v2, 0, pos);
         }
 #ifdef AF_F16S_TIMING
         {
@@ -782,6 +886,13 @@ template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XA
 __global__ __launch_bounds__(256, WPE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void af_conv_f16s(F16sArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16s_body<G, NSM, NSP, CT, KS, PS, OUT32, XACC, PJ, HD, DIST, WPE, 4 / PS, -1>(A, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// A whole residual block whose second convolution is 32 -> 32 (blocks 3 and 5) in one kernel: see "fused block" in f16s_body.
+template <class G, int NSM, int KS, int PS, bool XACC, int FU, int DIST>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_block_f16s(F16sArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16s_body<G, NSM, 0, 1, KS, PS, false, XACC, 1, 0, DIST, 1, 4 / PS, -1, FU>(A, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Small batches (r5; the drop-in Player evaluates ONE leaf per simulation): with <= 8 positions a launch is one workgroup per position
@@ -1471,6 +1582,28 @@ int launch_cfg(hipStream_t st, const F16sArgs& a, int gy, int ncu) {
     return 0;
 }
 
+// blocks 3 and 5 (11x11): both convolutions + the fused head in one launch (af_block_f16s)
+template <class G, int NSM, int KS, int PS, bool XACC, int FU>
+int launch_block(hipStream_t st, const F16sArgs& a, int ncu) {
+    constexpr int DIST = 2;                       // (a 5-slot ring + the activation slab + 36 KB of second-layer weights exceed 160 KB)
+    constexpr size_t scr = KS == 2 ? (size_t)PS * (4 / PS) * 4096 * 2 : 0;
+    constexpr size_t lds = Lds<G, DIST>::kScrOff + (scr > Lay<G>::kSlotL ? scr : Lay<G>::kSlotL) + 36864;
+    static_assert(lds <= 160 * 1024, "LDS budget of the fused block");
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    FS_HIP_OK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_block_f16s<G, NSM, KS, PS, XACC, FU, DIST>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_devs.fetch_or(bit, std::memory_order_relaxed);
+    }
+    const int gx = std::max(1, std::min(a.batch, ncu));
+    hipLaunchKernelGGL((af_block_f16s<G, NSM, KS, PS, XACC, FU, DIST>), dim3(gx), dim3(256), lds, st, a);
+    FS_HIP_OK(hipGetLastError());
+    return 0;
+}
+
 // 15x15, PS = 1 layers: the two half classes in one launch (af_conv_f16s_h15) + the corner pixel (af_corner_f16s) behind it
 template <class G, int NSM, int NSP, int CT, int KS, bool XACC>
 int launch_h15(hipStream_t st, F16sArgs a, int gy, int ncu) {
@@ -1719,6 +1852,7 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
     if (head >= 0) { a.hw = n->hcw[head]; a.hbias = n->hcb[head]; a.hx = n->hx[head]; a.inv_scale_h = n->hc_inv[head]; }
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
     a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xff) | (li << 8); a.gx0 = 0; a.stash = n->stash;
+    a.w2 = nullptr; a.bias2 = nullptr; a.inv_scale2 = 1.0f;
     a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
     return n->S == 11 ? launch_layer_g<Geo<11>>(n, st, li, a, head) : launch_layer_g<Geo<15>>(n, st, li, a, head);
 }
@@ -1742,9 +1876,26 @@ int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes, int batch) {
     return rc;
 }
 
+// F16sArgs of a fused block: the first convolution's (layer li) + the second one's weights / bias / scale + the head's
+static F16sArgs block_args(f16s_net* n, int li, const char* in, int batch, int head) {
+    F16sArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.w = n->w[li]; a.bias = n->bias[li]; a.inv_scale = n->inv_scale[li];
+    a.pw = n->pw[li]; a.inv_scale_p = n->inv_scale_p[li];
+    a.w2 = n->w[li + 1]; a.bias2 = n->bias[li + 1]; a.inv_scale2 = n->inv_scale[li + 1];
+    a.hw = n->hcw[head]; a.hbias = n->hcb[head]; a.hx = n->hx[head]; a.inv_scale_h = n->hc_inv[head];
+    a.batch = batch; a.abl = (n->abl & 0xff) | (li << 8); a.stash = n->stash;
+    return a;
+}
+
 int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3, int WP, int PP, float* value) {
-    int rc = launch_layer(n, st, 4, n->o[1], nullptr, n->g[2], nullptr, batch, 0, 0);
-    if (!rc) rc = launch_layer(n, st, 5, n->g[2], n->o[1], nullptr, o3, batch, WP, PP, value ? 0 : -1);
+    int rc;
+    if (n->S == 11 && value && !(n->abl & 256)) {          // (abl bit 8: the two-launch block, for A/B)
+        rc = launch_block<Geo<11>, 4, 2, 2, false, 1>(st, block_args(n, 4, n->o[1], batch, 0), n->ncu);
+    } else {
+        rc = launch_layer(n, st, 4, n->o[1], nullptr, n->g[2], nullptr, batch, 0, 0);
+        if (!rc) rc = launch_layer(n, st, 5, n->g[2], n->o[1], nullptr, o3, batch, WP, PP, value ? 0 : -1);
+    }
     if (!rc && value) {
         if (n->S == 11)
             hipLaunchKernelGGL(af_value_fc_f16s<Geo<11>>, dim3((batch + 31) / 32), dim3(128), 0, st, n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b,
@@ -1759,8 +1910,12 @@ int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3, int WP,
 int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP, int PP, float* policy) {
     int rc = launch_layer(n, st, 6, n->o[1], nullptr, n->g[3], nullptr, batch, 0, 0);
     if (!rc) rc = launch_layer(n, st, 7, n->g[3], n->o[1], n->o[3], nullptr, batch, 0, 0);
-    if (!rc) rc = launch_layer(n, st, 8, n->o[3], nullptr, n->g[4], nullptr, batch, 0, 0);
-    if (!rc) rc = launch_layer(n, st, 9, n->g[4], n->o[3], nullptr, o5, batch, WP, PP, policy ? 1 : -1);
+    if (!rc && n->S == 11 && policy && !(n->abl & 256)) {
+        rc = launch_block<Geo<11>, 2, 1, 4, true, 2>(st, block_args(n, 8, n->o[3], batch, 1), n->ncu);
+    } else {
+        if (!rc) rc = launch_layer(n, st, 8, n->o[3], nullptr, n->g[4], nullptr, batch, 0, 0);
+        if (!rc) rc = launch_layer(n, st, 9, n->g[4], n->o[3], nullptr, o5, batch, WP, PP, policy ? 1 : -1);
+    }
     if (!rc && policy) {
         if (n->S == 11)
             hipLaunchKernelGGL(af_policy_fc_f16s<Geo<11>>, dim3((batch + kPfPos - 1) / kPfPos), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],

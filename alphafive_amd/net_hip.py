@@ -140,7 +140,9 @@ _SPLIT_MAC_PER_PIXEL = sum(9 * ci * co + 9 * co * co + ci * co for ci, co in ((3
 #   blocks 3 and 5: the separately computed projection, fp32 in accumulator layout (16,384 B), written by conv1 and read by conv2
 #   head inputs: each branch's last conv also applies the head's 1x1 convolution and writes 4 (value) / 16 (policy) channels of
 #                121 pixels as fp16 halves (hi + lo), read once by the dense kernels; input planes; outputs
-_SPLIT_BYTES_PER_POSITION = (30 * 16384 + 19 * 15488 + 2 * 2 * 16384 + 2 * (4 + 16) * 121 * 2 * 2 + 3 * 121 * 4 + 122 * 4)
+# r5: blocks 3 and 5 run as ONE kernel each (af_block_f16s): their 32-channel intermediate and their projection never leave the CU —
+#   slab reads 30 -> 28, slab writes 19 -> 17, no fp32 projection buffers
+_SPLIT_BYTES_PER_POSITION = (28 * 16384 + 17 * 15488 + 2 * (4 + 16) * 121 * 2 * 2 + 3 * 121 * 4 + 122 * 4)
 
 
 def roofline_info(board_size=11):
@@ -157,9 +159,9 @@ def roofline_info(board_size=11):
     if board_size == 11:
         return {"backend": "hip (af_conv_f16s.hip: stem, convs and heads on v_mfma_f32_32x32x16_f16 with fp16 split operands and "
                            "fp32 accumulation; convs weight-stationary with an LDS-DMA slab ring)",
-                "kernel": "af_net_forward = af_stem_mfma_f16s + 10x af_conv_f16s (the last conv of each branch also applies the "
-                          "head's 1x1 convolution) + af_value_fc_f16s + af_policy_fc_f16s (whole forward timed; af_conv_f16s "
-                          "carries 99 % of the algorithmic FLOPs, each MAC issued as 3 fp16 MFMA MACs)",
+                "kernel": "af_net_forward = af_stem_mfma_f16s + 6x af_conv_f16s + 2x af_block_f16s (blocks 3 and 5: both convolutions "
+                          "and the head's 1x1 convolution in one kernel, the intermediate in LDS) + af_value_fc_f16s + af_policy_fc_f16s "
+                          "(whole forward timed; the convolution kernels carry 99 % of the algorithmic FLOPs, each MAC issued as 3 fp16 MFMA MACs)",
                 "peak_tflops": 2500.0, "issued_flop_per_position": 2 * 3 * _SPLIT_MAC_PER_PIXEL * 121,
                 "algorithmic_bytes_per_position": _SPLIT_BYTES_PER_POSITION}
     return {"backend": "hip (af_net.hip: fp32 MFMA Winograd F(2x2,3x3) convs, fused transforms/bias/ELU/residual)",
