@@ -138,3 +138,28 @@ def test_hip_evaluator_follows_weight_updates():
     p3, v3 = pv(xt)
     p64, v64 = net_fp64.forward(net.variables, x)
     assert np.abs(p3.cpu().numpy() - p64).max() < 1e-5 and np.abs(v3.cpu().numpy() - v64).max() < 1e-5
+
+
+@pytest.mark.parametrize("S,B,bits", [(11, 600, 256), (11, 5, 128 | 256), (15, 300, 64), (15, 3, 128)])
+def test_round5_launch_variants_are_bit_identical(S, B, bits):
+    """r5 added three launch structures that claim the SAME bits as the ones they replace: blocks 3 and 5 as one kernel each
+    (af_block_f16s; af_net_tune(7, 256) = two launches per block), the 15x15 half classes + corner kernel (af_conv_f16s_h15 /
+    af_corner_f16s; bit 64 = the two-halves launch) and the small-batch pixel-tile split (af_conv_f16s_sb; bit 128 = one workgroup
+    per position).  Same input through both structures: policy and value equal bit for bit."""
+    import torch
+    from alphafive_amd import net_hip
+    from alphafive_amd.network import ResNet
+    net = ResNet(S, device="cuda", seed=S + 1)
+    if S == 11:
+        net.load_npz(W)
+    xt = torch.from_numpy(_positions(S, B, seed=B)).cuda()
+    try:
+        pv = net.select_backend("hip")
+        p_new, v_new = (t.clone() for t in pv(xt))
+        net_hip.tune(7, bits)
+        p_old, v_old = (t.clone() for t in pv(xt))
+    finally:
+        net_hip.tune(7, 0)
+    assert torch.equal(p_new, p_old) and torch.equal(v_new, v_old)
+    p64, v64 = net_fp64.forward(net.variables, _positions(S, B, seed=B)[:8])
+    assert np.abs(v_new[:8].cpu().numpy() - v64).max() < 1e-5
