@@ -24,6 +24,9 @@ int f16s_trunk(f16s_net* n, hipStream_t st, const float* planes_dev, int batch);
 // same split-operand MFMA (af_value_fc_f16s / af_policy_fc_f16s) -> value [batch] / policy [batch][121]; o3 / o5 are then not written
 int f16s_value_branch(f16s_net* n, hipStream_t st, int batch, float* o3_dev, int WP, int PP, float* value);
 int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5_dev, int WP, int PP, float* policy);
+// batches <= 8 on 11x11, heads fused: both branches on one stream ({policy conv1 || value block} in one launch): no side stream
+int f16s_small_branches_ok(const f16s_net* n, int batch);          // (abl bit 9 = the two-stream form, for A/B)
+int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, float* policy);
 void f16s_set_ablation(f16s_net* n, int bits);
 int f16s_read_activation(f16s_net* n, int which, int batch, float* host);
 

@@ -895,6 +895,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     f16s_body<G, NSM, 0, 1, KS, PS, false, XACC, 1, 0, DIST, 1, 4 / PS, -1, FU>(A, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// Small batches, 11x11: the first convolution of the policy branch (128 -> 64, pixel tiles split over two workgroups per position) and the
+// whole value block (af_block_f16s's body) depend on the trunk only — one launch runs both as two workgroup classes, so that the value
+// branch needs no second stream: at batch 1 the fork and the join of the side stream were 12 + 10 us of a 124-us tick
+// (profiles/r5_22_selfplay_timeline.txt), more than the value branch's own kernels take.
+template <class G>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_small_pair_f16s(F16sArgs P, F16sArgs V) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nb = P.batch, id = (int)blockIdx.x;
+    if (id < 2 * nb) f16s_body<G, 4, 0, 2, 2, 1, false, false, 0, 0, kDist, 1, 2, -1>(P, smem, id % nb, nb, (id / nb) * 2);
+    else f16s_body<G, 4, 0, 1, 2, 2, false, false, 1, 0, 2, 1, 2, -1, 1>(V, smem, id - 2 * nb, nb);
+}
+
 // Small batches (r5; the drop-in Player evaluates ONE leaf per simulation): with <= 8 positions a launch is one workgroup per position
 // that works through all four pixel tiles — 14-16 k cycles of MFMAs in the wide layers next to an 8 k-cycle start-up
 // (profiles/r5_14_f16s_phases_batch1.txt).  Here gridDim.z workgroups share a pseudo-position, NTW tiles per wave each (1 where every
@@ -1208,14 +1220,17 @@ __global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict
 // ----------------------------------------------------------------------------------------------------------------------------
 // value: fc1 4*S*S -> 64 + ELU, fc2 64 -> 1, tanh(x/2).  Workgroup = 32 positions x 2 waves (cout tile mt of 32).  The whole job
 // is 93 (171 at 15x15) MFMAs per wave: what matters is that a wave's operand loads are all in flight at once (batches of 16 k-steps).
+// (the body: a workgroup of 128 threads — or of 256 whose upper half repeats the lower half's arithmetic and stores nothing, so that
+// the small-batch launch can run it as one workgroup class of a 256-thread kernel: af_small_l7v_f16s)
 template <class G>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void af_value_fc_f16s(
-    const char* __restrict__ xv, const uint4* __restrict__ a /*[VSTEPS][2][hi|lo][64]*/, const float* __restrict__ b1, const float* __restrict__ w2,
-    const float* __restrict__ b2, float inv_scale, float* __restrict__ value, int batch) {
+__device__ __forceinline__ void f16s_vfc_body(const char* __restrict__ xv, const uint4* __restrict__ a, const float* __restrict__ b1,
+                                              const float* __restrict__ w2, const float* __restrict__ b2, float inv_scale,
+                                              float* __restrict__ value, int batch, const int bx) {
     __shared__ float red[2][32];
     constexpr int NS = Hx<G>::VSTEPS;
-    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, n = lane & 31, kg = lane >> 5;
-    const int pos = (int)blockIdx.x * 32 + n, posc = pos < batch ? pos : batch - 1;
+    const bool act = threadIdx.x < 128;
+    const int lane = threadIdx.x & 63, mt = (threadIdx.x >> 6) & 1, n = lane & 31, kg = lane >> 5;
+    const int pos = bx * 32 + n, posc = pos < batch ? pos : batch - 1;
     const char* xb = xv + (size_t)posc * Hx<G>::kValPos + (uint32_t)kg * 16u;
     const uint4* ap = a + (size_t)mt * 128 + lane;                          // + step * 256 + half * 64
     f32x16 acc;
@@ -1263,9 +1278,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         part += elu1(acc[r] * inv_scale + b1[j]) * w2[j];
     }
     part += __shfl_xor(part, 32);
-    if (kg == 0) red[mt][n] = part;
+    if (act && kg == 0) red[mt][n] = part;
     __syncthreads();
-    if (mt == 0 && kg == 0 && pos < batch) value[pos] = tanhf((red[0][n] + red[1][n] + b2[0]) * 0.5f);
+    if (act && mt == 0 && kg == 0 && pos < batch) value[pos] = tanhf((red[0][n] + red[1][n] + b2[0]) * 0.5f);
+}
+template <class G>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void af_value_fc_f16s(
+    const char* __restrict__ xv, const uint4* __restrict__ a /*[VSTEPS][2][hi|lo][64]*/, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, float inv_scale, float* __restrict__ value, int batch) {
+    f16s_vfc_body<G>(xv, a, b1, w2, b2, inv_scale, value, batch, (int)blockIdx.x);
+}
+// Small batches, 11x11: the policy branch's second convolution (64 -> 64 + projection, tiles split over two workgroups per position)
+// next to the value head's dense layers (one more workgroup; both depend on af_small_pair_f16s only) in one launch
+struct VfcArgs { const char* xv; const uint4* a; const float *b1, *w2, *b2; float inv_scale; float* value; };
+template <class G>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_small_l7v_f16s(F16sArgs P, VfcArgs V) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nb = P.batch, id = (int)blockIdx.x;
+    if (id < 2 * nb) f16s_body<G, 2, 4, 2, 2, 1, false, true, 0, 0, kDist, 1, 2, -1>(P, smem, id % nb, nb, (id / nb) * 2);
+    else f16s_vfc_body<G>(V.xv, V.a, V.b1, V.w2, V.b2, V.inv_scale, V.value, nb, id - 2 * nb);
 }
 
 // policy: fc 16*S*S -> S*S, softmax.  Workgroup = 32 positions x 8 waves = (MT tiles of 32 logits: mt, mt + 4, ...) x (half of K):
@@ -1926,6 +1957,54 @@ int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP
     }
     return rc;
 }
+
+// Small batches on 11x11 (heads fused): both branches on ONE stream — {policy conv1 || value block} as one launch, the value head's
+// dense layers, then the rest of the policy branch.  The same kernels' bodies with the same arguments: the same bits.
+int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, float* policy) {
+    if (!n || n->S != 11 || batch < 1 || batch > kSmallBatch || !value || !policy) return -1;
+    using G = Geo<11>;
+    F16sArgs P;
+    memset(&P, 0, sizeof(P));
+    P.in = n->o[1]; P.w = n->w[6]; P.bias = n->bias[6]; P.out = n->g[3]; P.inv_scale = n->inv_scale[6];
+    P.batch = batch; P.abl = (n->abl & 0xff) | (6 << 8); P.stash = n->stash; P.inv_scale2 = 1.0f; P.inv_scale_h = 1.0f;
+    const F16sArgs V = block_args(n, 4, n->o[1], batch, 0);
+    constexpr size_t ldsP = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 2 * 4096;                       // CT = 2, PS = 1, NTW = 2
+    constexpr size_t ldsV = Lds<G, 2>::kScrOff + (size_t)2 * 2 * 4096 * 2 + 36864;
+    constexpr size_t lds = ldsP > ldsV ? ldsP : ldsV;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    FS_HIP_OK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_small_pair_f16s<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_devs.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(af_small_pair_f16s<G>, dim3(3 * batch), dim3(256), lds, st, P, V);
+    FS_HIP_OK(hipGetLastError());
+    {
+        F16sArgs Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.in = n->g[3]; Q.in2 = n->o[1]; Q.w = n->w[7]; Q.bias = n->bias[7]; Q.out = n->o[3]; Q.inv_scale = n->inv_scale[7];
+        Q.batch = batch; Q.abl = (n->abl & 0xff) | (7 << 8); Q.stash = n->stash; Q.inv_scale2 = 1.0f; Q.inv_scale_h = 1.0f;
+        const VfcArgs F = {n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b, n->hf_inv[0], value};
+        constexpr size_t lds7 = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 2 * 4096;
+        static std::atomic<uint64_t> attr7{0};
+        if (!(attr7.load(std::memory_order_relaxed) & bit)) {
+            // (the kernel also has 256 bytes of static LDS — the value head's reduction buffer: dynamic + static must stay within 160 KB)
+            FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_small_l7v_f16s<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7));
+            attr7.fetch_or(bit, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL(af_small_l7v_f16s<G>, dim3(2 * batch + 1), dim3(256), lds7, st, Q, F);
+        FS_HIP_OK(hipGetLastError());
+    }
+    int rc = launch_block<G, 2, 1, 4, true, 2>(st, block_args(n, 8, n->o[3], batch, 1), n->ncu);
+    if (!rc) hipLaunchKernelGGL(af_policy_fc_f16s<G>, dim3((batch + kPfPos - 1) / kPfPos), dim3(512), kPfLds, st, n->hx[1], n->hfw[1], n->hfb[1],
+                                n->hf_inv[1], policy, batch);
+    FS_HIP_OK(hipGetLastError());
+    return rc;
+}
+int f16s_small_branches_ok(const f16s_net* n, int batch) { return n && n->S == 11 && batch <= kSmallBatch && !(n->abl & (128 | 256 | 512)); }
 
 // debug / tests: activation `which` (0 f0, 1 g1, 2 o1, 3 g2, 4 o2, 5 g3, 6 g4, 7 o4, 8 g5) of the first `batch` positions as
 // fp32 [batch][C][S*S] on the host (hi + lo).  Returns the channel count or < 0.

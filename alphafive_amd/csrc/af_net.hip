@@ -1302,6 +1302,12 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     } else {
         hipLaunchKernelGGL(af_stem_conv, dim3(batch), dim3(256), 0, st, planes, n->stem_w, n->stem_b, f0, S, WP, PP);
     }
+    if (fhead && f16s_small_branches_ok(n->f16s, batch)) {
+        // small batches: fork and join of the value branch's side stream cost more than its kernels (af_conv_f16s.hip)
+        if (f16s_small_branches(n->f16s, st, batch, value, policy)) return AF_NET_ERR_HIP;
+        NET_HIP_OK(hipGetLastError());
+        return AF_NET_OK;
+    }
     const float* block_in[5] = {f0, o[0], o[1], o[1], o[3]};
     // the value branch (block3 + head) only depends on the trunk output o[1]: it runs on a side stream,
     // concurrently with the policy branch (blocks 4,5 + head), filling the SIMDs the 32/64-wide layers leave idle
