@@ -907,6 +907,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     else f16s_body<G, 4, 0, 1, 2, 2, false, false, 1, 0, 2, 1, 2, -1, 1>(V, smem, id - 2 * nb, nb);
 }
 
+// ... and the same pairing at full batch (r5): the first P.gx0 workgroups are the policy branch's first convolution (one per CU, walking the
+// positions), the rest the value block; the hardware places workgroups in index order, so the value block's workgroups start on CUs as
+// the policy layer's finish — the tail filling the side stream was kept for, without its fork and join.
+template <class G>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_big_pair_f16s(F16sArgs P, F16sArgs V) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gp = P.gx0, id = (int)blockIdx.x;
+    if (id < gp) f16s_body<G, 4, 0, 2, 2, 1, false, false, 0, 0, kDist, 1, 4, -1>(P, smem, id, gp);
+    else f16s_body<G, 4, 0, 1, 2, 2, false, false, 1, 0, 2, 1, 2, -1, 1>(V, smem, id - gp, (int)gridDim.x - gp);
+}
+
 // Small batches (r5; the drop-in Player evaluates ONE leaf per simulation): with <= 8 positions a launch is one workgroup per position
 // that works through all four pixel tiles — 14-16 k cycles of MFMAs in the wide layers next to an 8 k-cycle start-up
 // (profiles/r5_14_f16s_phases_batch1.txt).  Here gridDim.z workgroups share a pseudo-position, NTW tiles per wave each (1 where every
@@ -1297,6 +1308,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int nb = P.batch, id = (int)blockIdx.x;
     if (id < 2 * nb) f16s_body<G, 2, 4, 2, 2, 1, false, true, 0, 0, kDist, 1, 2, -1>(P, smem, id % nb, nb, (id / nb) * 2);
     else f16s_vfc_body<G>(V.xv, V.a, V.b1, V.w2, V.b2, V.inv_scale, V.value, nb, id - 2 * nb);
+}
+// ... and at full batch: P.gx0 workgroups of the policy branch's second convolution, then one workgroup per 32 positions of the value head
+template <class G>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_big_l7v_f16s(F16sArgs P, VfcArgs V) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gp = P.gx0, id = (int)blockIdx.x;
+    if (id < gp) f16s_body<G, 2, 4, 2, 2, 1, false, true, 0, 0, kDist, 1, 4, -1>(P, smem, id, gp);
+    else f16s_vfc_body<G>(V.xv, V.a, V.b1, V.w2, V.b2, V.inv_scale, V.value, P.batch, id - gp);
 }
 
 // policy: fc 16*S*S -> S*S, softmax.  Workgroup = 32 positions x 8 waves = (MT tiles of 32 logits: mt, mt + 4, ...) x (half of K):
@@ -1961,14 +1980,15 @@ int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5, int WP
 // Small batches on 11x11 (heads fused): both branches on ONE stream — {policy conv1 || value block} as one launch, the value head's
 // dense layers, then the rest of the policy branch.  The same kernels' bodies with the same arguments: the same bits.
 int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, float* policy) {
-    if (!n || n->S != 11 || batch < 1 || batch > kSmallBatch || !value || !policy) return -1;
+    if (!n || n->S != 11 || batch < 1 || !value || !policy) return -1;
     using G = Geo<11>;
+    const bool small = batch <= kSmallBatch;
     F16sArgs P;
     memset(&P, 0, sizeof(P));
     P.in = n->o[1]; P.w = n->w[6]; P.bias = n->bias[6]; P.out = n->g[3]; P.inv_scale = n->inv_scale[6];
     P.batch = batch; P.abl = (n->abl & 0xff) | (6 << 8); P.stash = n->stash; P.inv_scale2 = 1.0f; P.inv_scale_h = 1.0f;
     const F16sArgs V = block_args(n, 4, n->o[1], batch, 0);
-    constexpr size_t ldsP = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 2 * 4096;                       // CT = 2, PS = 1, NTW = 2
+    constexpr size_t ldsP = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 4 * 4096;                       // CT = 2, PS = 1, NTW = 4 (2 at small batches)
     constexpr size_t ldsV = Lds<G, 2>::kScrOff + (size_t)2 * 2 * 4096 * 2 + 36864;
     constexpr size_t lds = ldsP > ldsV ? ldsP : ldsV;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -1978,9 +1998,16 @@ int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, fl
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
         FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_small_pair_f16s<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_big_pair_f16s<G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_devs.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(af_small_pair_f16s<G>, dim3(3 * batch), dim3(256), lds, st, P, V);
+    const int gp = std::max(1, std::min(batch, n->ncu));          // workgroups of a class at full batch: one per CU
+    if (small) {
+        hipLaunchKernelGGL(af_small_pair_f16s<G>, dim3(3 * batch), dim3(256), lds, st, P, V);
+    } else {
+        P.gx0 = gp;
+        hipLaunchKernelGGL(af_big_pair_f16s<G>, dim3(2 * gp), dim3(256), lds, st, P, V);
+    }
     FS_HIP_OK(hipGetLastError());
     {
         F16sArgs Q;
@@ -1988,14 +2015,20 @@ int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, fl
         Q.in = n->g[3]; Q.in2 = n->o[1]; Q.w = n->w[7]; Q.bias = n->bias[7]; Q.out = n->o[3]; Q.inv_scale = n->inv_scale[7];
         Q.batch = batch; Q.abl = (n->abl & 0xff) | (7 << 8); Q.stash = n->stash; Q.inv_scale2 = 1.0f; Q.inv_scale_h = 1.0f;
         const VfcArgs F = {n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b, n->hf_inv[0], value};
-        constexpr size_t lds7 = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 2 * 4096;
+        constexpr size_t lds7 = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 4 * 4096;
         static std::atomic<uint64_t> attr7{0};
         if (!(attr7.load(std::memory_order_relaxed) & bit)) {
-            // (the kernel also has 256 bytes of static LDS — the value head's reduction buffer: dynamic + static must stay within 160 KB)
+            // (the kernels also have 256 bytes of static LDS — the value head's reduction buffer: dynamic + static must stay within 160 KB)
             FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_small_l7v_f16s<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7));
+            FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_big_l7v_f16s<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7));
             attr7.fetch_or(bit, std::memory_order_relaxed);
         }
-        hipLaunchKernelGGL(af_small_l7v_f16s<G>, dim3(2 * batch + 1), dim3(256), lds7, st, Q, F);
+        if (small) {
+            hipLaunchKernelGGL(af_small_l7v_f16s<G>, dim3(2 * batch + 1), dim3(256), lds7, st, Q, F);
+        } else {
+            Q.gx0 = gp;
+            hipLaunchKernelGGL(af_big_l7v_f16s<G>, dim3(gp + (batch + 31) / 32), dim3(256), lds7, st, Q, F);
+        }
         FS_HIP_OK(hipGetLastError());
     }
     int rc = launch_block<G, 2, 1, 4, true, 2>(st, block_args(n, 8, n->o[3], batch, 1), n->ncu);
@@ -2004,7 +2037,11 @@ int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, fl
     FS_HIP_OK(hipGetLastError());
     return rc;
 }
-int f16s_small_branches_ok(const f16s_net* n, int batch) { return n && n->S == 11 && batch <= kSmallBatch && !(n->abl & (128 | 256 | 512)); }
+// (abl bit 9: the two-stream form at small batches; bit 10: at full batch — for A/B)
+int f16s_small_branches_ok(const f16s_net* n, int batch) {
+    if (!n || n->S != 11 || (n->abl & 256)) return 0;
+    return batch <= kSmallBatch ? !(n->abl & (128 | 512)) : !(n->abl & 1024);
+}
 
 // debug / tests: activation `which` (0 f0, 1 g1, 2 o1, 3 g2, 4 o2, 5 g3, 6 g4, 7 o4, 8 g5) of the first `batch` positions as
 // fp32 [batch][C][S*S] on the host (hi + lo).  Returns the channel count or < 0.
