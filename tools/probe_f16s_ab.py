@@ -31,6 +31,8 @@ def child():
     hn = net_hip.HipNet(net.variables, S, B, "cuda")
     x = _positions(S, B, seed=1)
     xb = torch.from_numpy(x).cuda()
+    if os.environ.get("BRANCH") is not None:
+        net_hip.tune(4, int(os.environ["BRANCH"]))           # value branch on its side stream (1, default) or serialised on the main stream (0)
     if os.environ.get("ABLBITS"):
         net_hip.tune(7, int(os.environ["ABLBITS"]))          # af_conv_f16s ablation / A-B bits (16 = the VALU stem)
     for _ in range(10):
