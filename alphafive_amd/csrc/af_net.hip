@@ -1311,8 +1311,11 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     const float* block_in[5] = {f0, o[0], o[1], o[1], o[3]};
     // the value branch (block3 + head) only depends on the trunk output o[1]: it runs on a side stream,
     // concurrently with the policy branch (blocks 4,5 + head), filling the SIMDs the 32/64-wide layers leave idle
+    // (r5: on the split-operand path the side stream is used by neither board size any more — 11x11 runs the value branch as workgroup
+    //  classes of the policy branch's launches (f16s_small_branches above); 15x15 serialised is 0.7 % faster than forked, 2.653 vs 2.672 ms:
+    //  fork and join cost more than the tail filling returns.  af_net_tune(4, 2) forces the side stream for A/B.)
     hipStream_t vs = st;
-    if (g_branch && n->branch_stream) {
+    if (g_branch && n->branch_stream && (!split16 || g_branch == 2)) {
         vs = n->branch_stream;
     }
     for (int i = split16 ? 2 : 0; i < 5; ++i) {
