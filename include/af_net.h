@@ -48,8 +48,14 @@ int af_net_forward(af_net* n, void* stream, const float* planes_dev, int32_t bat
  *          persistent grid, 0 fp32 direct implicit GEMM
  *   key 1: number of sub-batch side streams (default 1)      key 2: sub-batch size (0 = batch / streams)
  *   key 3: ablation variant of the Winograd kernel (profiling only; results are wrong by design)
- *   key 4: value branch on a side stream (default 1)         key 5: MFMA policy head (default 1)
- *   key 6: workgroups of the persistent variant (default 256)   key 7: ablation bits of path 5 (profiling)
+ *   key 4: value branch on a side stream (default 1: on the fp32 paths only; since r5 path 5 runs both branches on one stream —
+ *          2 forces the side stream there too, for A/B)           key 5: MFMA policy head (default 1)
+ *   key 6: workgroups of the persistent variant (default 256)
+ *   key 7: bits of path 5 — 1 / 2 / 4 profiling ablations (results wrong by design), 16 VALU stem, 32 one workgroup per CU in the
+ *          32-channel-input layers; r5 launch structures, each bit selecting the launch it replaced (same results bit for bit):
+ *          64 two-halves launch on 15x15 (instead of the 4-tile / 3-tile classes + corner kernel), 128 one workgroup per position at
+ *          batches <= 8 (instead of the pixel-tile split), 256 two launches per 32-wide block (instead of af_block_f16s),
+ *          512 / 1024 the two-branch launch order at batches <= 8 / above (instead of the value branch as a workgroup class)
  *   key 8: sequential sub-batches on one stream (default 1 = none; measured slower)
  *   key 9: path 5 computes the heads itself — 1x1 head convolutions fused into the last conv of each branch, dense layers on
  *          the same split-operand MFMA (default 1); 0 = the fp32 head kernels of the other paths on fp32 planes */
