@@ -126,6 +126,9 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 #ifndef AF_TICK_NOISE_PAIR
 #define AF_TICK_NOISE_PAIR 0      // r5 A/B record (profiles/r5_03_tick_ab.txt): clean-up rounds with two attempts side by side — same bits, +5.5 % per launch: off
 #endif
+#ifndef AF_TICK_PAIR_FROM
+#define AF_TICK_PAIR_FROM 4
+#endif
 #ifndef AF_TICK_ROOT_TERM
 #define AF_TICK_ROOT_TERM 1       // r5: depth-0 terminal test: two-sided for EXTERNAL-mode roots, none in self-play (see the descent)
 #endif
@@ -934,6 +937,9 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
 #endif
                     todo = pend;
 #if AF_TICK_NOISE_PAIR
+                    // (AF_TICK_NOISE_PAIR = 2: only from the AF_TICK_PAIR_FROM-th select of a launch on — the waves that run that many selects
+                    //  are the launch's tail, alone on their SIMD, where the second chain is free; both loops give the same bits)
+                    if (AF_TICK_NOISE_PAIR == 1 || work >= AF_TICK_PAIR_FROM) {
                     // Clean-up rounds, two attempts side by side (r5).  A rejected cell continues with attempts 1, 2, ... of ITS counter
                     // sequence (attempt a = words 2(a&1), 2(a&1)+1 of block a>>1), so whatever is evaluated speculatively, the variate is
                     // the first accepted attempt = af_gamma_lt1's.  Slot A = the lane's first pending cell's next attempt; slot B = the
@@ -983,7 +989,9 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                         }
                         todo &= ~((doneA ? (1u << ka) : 0u) | (doneB ? (1u << kb) : 0u));
                     }
-#else
+                    } else
+#endif
+                    {
                     uint32_t it = 1;
                     af_u32x4 r = rk[0];
 #pragma unroll
@@ -1009,7 +1017,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                             ++it;
                         }
                     }
-#endif
+                    }
 #else
                     uint32_t it = 0;
                     af_u32x4 r;
