@@ -234,3 +234,6 @@ class ResNet(object):
             for _, fn in self._hip_eval.values():
                 fn.close()
             self._hip_eval.clear()
+        # a HIP graph captured over a released evaluator's buffers must not be replayed: graphs are keyed on the weight version
+        # (Player._search_batch, SelfPlayEngine.run_ticks_graph), so a net that is used again after close() re-captures
+        self.version = getattr(self, "version", 0) + 1
