@@ -44,7 +44,7 @@ def test_bench_line_carries_the_contract():
     assert abs(r["frac_of_sustained_peak"] - r["achieved"] / r["sustained_peak_tflops"]) < 1e-9
     assert abs(r["mfma_issued_frac_of_sustained_peak"] - r["mfma_issued_tflops"] / r["sustained_peak_tflops"]) < 1e-9
     pk = r["per_kernel"]
-    assert len(pk) >= 12 and all(set(("kernel", "us", "ghz", "mfma_busy", "mfma_issued_tflops", "hbm_mb")) <= set(e) for e in pk)
+    assert len(pk) >= 8 and all(set(("kernel", "us", "ghz", "mfma_busy", "mfma_issued_tflops", "hbm_mb")) <= set(e) for e in pk)
     assert abs(sum(e["us"] * e["launches_per_forward"] for e in pk) - r["profiled_forward_us"]) < 1e-6 * r["profiled_forward_us"]
     assert abs(sum(e["hbm_mb"] * e["launches_per_forward"] for e in pk) * 1e6 - r["traffic"]) < 0.01 * r["traffic"]
     # the forward as it runs inside the graph: replay time per tick - tick kernel; what lies outside the replays is small
