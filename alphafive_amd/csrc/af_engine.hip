@@ -75,7 +75,17 @@ struct EngineParams {
     u64* counters;
     u64* progress;   // [0] plies committed, [1] episodes finished (all games)
     u64* hist;       // HIST_N words, all games
+    // evaluation memo (ABI v5, off unless af_engine_memo_enable was called): (position, last move) -> the net's policy and value,
+    // shared by all games of the engine.  4-way buckets; a launch only reads it (the tick kernel) or only writes it (af_memo_insert)
+    u64* memo_key;   // [4 * buckets][4 KW]: 2 KW key words, (1 << 32 | last + 1), zeros; an empty entry is all zeros
+    float* memo_pv;  // [4 * buckets][CP]: C policy floats as the net wrote them, the value at [C]
+    u64* memo_lock;  // [4 * buckets]: serial of the launch that last wrote the entry (one writer per entry and launch)
+    u64* memo_stats; // MEMO_SERIAL, MEMO_PROBES, MEMO_HITS, MEMO_INSERTS, MEMO_REPLACED
+    uint32_t memo_bucket_mask;
+    int memo_max_stones;
+    int memo_budget;     // selects per launch after which a game that has consumed a memo hit yields (AF_MEMO_BUDGET; default min(budget, 6))
 };
+enum { MEMO_SERIAL = 0, MEMO_PROBES, MEMO_HITS, MEMO_INSERTS, MEMO_REPLACED, MEMO_N };
 
 // ----------------------------------------------------------------------------------------------
 // device helpers
@@ -376,6 +386,46 @@ __device__ int tree_lookup(const EngineParams& P, int g, const u64* mine, const 
     return -1;
 }
 
+// ---- evaluation memo ----
+// The net is a pure function of (stones, last move) and the forward is independent of batch slot and batch size to the bit
+// (tests/test_gpu_net.py), so the evaluation of a position ANY game of the engine has parked on before can be consumed at once
+// instead of waiting a tick for the same bits.  Every game still owns its tree (player.py:38: one tree per Player): only the
+// pipe round trip of player.py:194-197 is short-cut.  One bucket = 4 entries of 4 KW words = one word per lane.
+template <int KW>
+__device__ __forceinline__ uint32_t memo_bucket(const EngineParams& P, const u64* mine, const u64* theirs, int last) {
+    uint32_t h = key_hash<KW>(mine, theirs) ^ ((uint32_t)(last + 1) * 0x9E3779B1u);
+    h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+    return h & P.memo_bucket_mask;
+}
+template <int KW>
+__device__ __forceinline__ u64 memo_word(const u64* mine, const u64* theirs, int last, int w) {   // word w of the entry's key row
+    const u64 kw = key_word<KW>(mine, theirs, w);                                                // (0 for w >= 2 KW)
+    return w == 2 * KW ? ((1ull << 32) | (u64)(uint32_t)(last + 1)) : kw;
+}
+// -> entry index or -1; *empty_ways = bit v set iff way v of the bucket has never been written
+template <int KW>
+__device__ __forceinline__ int memo_probe(const EngineParams& P, uint32_t bucket, const u64* mine, const u64* theirs, int last, int lane,
+                                          uint32_t* empty_ways) {
+    constexpr int MK = 4 * KW;
+    const int w = lane & (MK - 1);
+    const u64 expect = memo_word<KW>(mine, theirs, last, w);
+    u64 have = expect;
+    if (lane < 4 * MK) have = P.memo_key[(size_t)bucket * (4 * MK) + lane];
+    const u64 bad = __ballot(have != expect);
+    const u64 blank = __ballot(lane < 4 * MK && w == 2 * KW && have == 0ull);
+    uint32_t em = 0;
+    int hit = -1;
+#pragma unroll
+    for (int v = 3; v >= 0; --v) {
+        const u64 wm = (MK == 16 ? 0xffffull : 0xffull) << (v * MK);
+        if ((bad & wm) == 0ull) hit = (int)bucket * 4 + v;
+        if (blank & wm) em |= 1u << v;
+    }
+    *empty_ways = em;
+    return hit;
+}
+
+
 // numpy float32 add.reduce restated (pairwise, 8 accumulators) over an LDS array
 __device__ float pairwise_block(const float* a, int n) {
     if (n < 8) {
@@ -418,7 +468,7 @@ __device__ unsigned long long g_tick_cycles[8192][13];      // 8..11: inside the
 #define TK_ACC(slot, a, b)
 #endif
 
-template <int KW, bool W64>
+template <int KW, bool W64, bool MEMO = false>
 __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EngineParams P, const float* __restrict__ policy_in,
                                                      const float* __restrict__ value_in, float* __restrict__ planes_out) {
     constexpr int CP = 64 * KW;
@@ -427,6 +477,9 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     const int C = P.C, NCAP = P.node_cap;
+    if constexpr (MEMO) {                            // the launch serial af_memo_insert claims entries with
+        if (g == 0 && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&P.memo_stats[MEMO_SERIAL]), 1ull);
+    }
 
     int phase = rfli(P.phase[g]);
     if (phase == PH_IDLE || phase == PH_MOVE_DONE || phase == PH_ERROR) return;
@@ -494,21 +547,39 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
     TK_T(tk_loaded);
     TK_ACC(0, tk_entry, tk_loaded);
     // ---- 1. consume the evaluation of the parked leaf: player.py:186-202 + :166 ----
-    if (rfli(P.pending[g])) {
-        u64 lm[KW], lt[KW], legal[KW];
+    // (MEMO: also of a leaf whose evaluation the memo holds — found in the descent below, consumed here, and the game goes on)
+    u64 lm[KW], lt[KW];
+    int c_depth = 0;
+    uint32_t c_slot = 0;
+    const float* c_pol = policy_in + (size_t)g * C;
+    const float* c_val = value_in + g;
+    bool have_eval = rfli(P.pending[g]) != 0;
+    if (have_eval) {
 #pragma unroll
         for (int k = 0; k < KW; ++k) {
             lm[k] = rfl64(P.leaf[(size_t)g * 2 * KW + k]);
             lt[k] = rfl64(P.leaf[(size_t)g * 2 * KW + KW + k]);
-            legal[k] = ~(lm[k] | lt[k]) & P.boardmask[k];
         }
-        const int depth = rfli(P.depth[g]);
-        const uint32_t slot = rfl32((uint32_t)P.leaf_slot[g]);
+        c_depth = rfli(P.depth[g]);
+        c_slot = rfl32((uint32_t)P.leaf_slot[g]);
+    }
+    int status = AF_STATUS_IDLE;
+    bool parked = false;
+    int work = 0;   // selects done in this launch
+    uint32_t memo_probes = 0, memo_hits = 0;
+  for (;;) {
+    if (have_eval) {
+        have_eval = false;
+        u64 legal[KW];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) legal[k] = ~(lm[k] | lt[k]) & P.boardmask[k];
+        const int depth = c_depth;
+        const uint32_t slot = c_slot;
         float pk[KW];
 #pragma unroll
         for (int k = 0; k < KW; ++k) {
             const int c = lane + 64 * k;
-            pk[k] = ((legal[k] >> lane) & 1ull) ? policy_in[(size_t)g * C + c] : 0.0f;
+            pk[k] = ((legal[k] >> lane) & 1ull) ? c_pol[c] : 0.0f;
         }
         // all_p: left-to-right fp32 sum in row-major legal order (SURVEY §8a rule 1; the zeros of the occupied cells change nothing).
         // Every lane adds the same broadcast LDS values in the same order: a chain of 64 KW dependent adds with the operands
@@ -544,7 +615,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 ep[off] = ((legal[k] >> lane) & 1ull) ? pk[k] / s : 0.0f;
             }
             __syncthreads();
-            backup(depth, rflf(value_in[g]), 1);
+            backup(depth, rflf(*c_val), 1);
             ct[CT_EXPANDS]++;
             ct[CT_LEXP] += (uint32_t)bb_count<KW>(legal);
         }
@@ -552,21 +623,17 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
         sims_left--;
     }
 
-    int status = AF_STATUS_IDLE;
-    bool parked = false;
-    int work = 0;   // selects done in this launch
-
     TK_T(tk_consumed);
     TK_ACC(1, tk_loaded, tk_consumed);
     // ---- 2. advance until the game parks ----
-    while (!parked && !err) {
+    while (!parked && !err && !(MEMO && have_eval)) {
         TK_T(tk_iter);
         // A launch lasts as long as its slowest game.  Simulations that end in a terminal position need no
         // evaluation, so a game whose root has a decided child could run hundreds of them back to back while
         // every other wave has long parked; after `budget` selects the game yields at the next simulation
         // boundary instead (its slot of the leaf batch idles for one tick; the order of simulations inside
         // the game, and so every result, is unchanged).
-        if (work >= P.budget && phase != PH_DESCENT) { status = AF_STATUS_YIELD; parked = true; ct[CT_YIELDS]++; break; }
+        if (work >= ((MEMO && memo_hits) ? P.memo_budget : P.budget) && phase != PH_DESCENT) { status = AF_STATUS_YIELD; parked = true; ct[CT_YIELDS]++; break; }
         if (phase == PH_MOVE_START) {
             // SELFPLAY back-pressure (the reference's Queue(50), main.py:51,94): an episode may only start
             // when its record buffer has been popped; until then the game waits here.
@@ -838,6 +905,24 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                 if (idx >= 0 && pidx >= 0 && lane == 0) ec[(size_t)pidx * CP + pcl] = idx + 1;   // reached through another move order before
             }
             if (idx < 0) {                                                  // :218 unseen -> park for the net
+                if constexpr (MEMO) {
+                    // ... unless the memo holds this (position, last move): expand from it now, at the top of the outer loop
+                    if (slot != 0xffffffffu && bb_count<KW>(cm) + bb_count<KW>(ctb) <= P.memo_max_stones) {
+                        uint32_t unused;
+                        const int me = memo_probe<KW>(P, memo_bucket<KW>(P, cm, ctb, last), cm, ctb, last, lane, &unused);
+                        ++memo_probes;
+                        if (me >= 0) {
+                            ++memo_hits;
+#pragma unroll
+                            for (int k = 0; k < KW; ++k) { lm[k] = cm[k]; lt[k] = ctb[k]; }
+                            c_depth = depth; c_slot = slot;
+                            c_pol = P.memo_pv + (size_t)me * CP;
+                            c_val = c_pol + C;
+                            have_eval = true;
+                            break;
+                        }
+                    }
+                }
                 if (lane < 2 * KW) P.leaf[(size_t)g * 2 * KW + lane] = key_word<KW>(cm, ctb, lane);
                 if (lane == 0) { P.depth[g] = depth; P.leaf_last[g] = last; P.leaf_slot[g] = (int32_t)slot; }
                 // utils.py:256 board_to_inputs -> float32[3][S][S]
@@ -1160,7 +1245,15 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
 #endif
         }
     }
+    if (!MEMO || !have_eval) break;
+  }
     TK_T(tk_parked);
+    if constexpr (MEMO) {
+        if (lane == 0 && memo_probes) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&P.memo_stats[MEMO_PROBES]), (unsigned long long)memo_probes);
+            if (memo_hits) atomicAdd(reinterpret_cast<unsigned long long*>(&P.memo_stats[MEMO_HITS]), (unsigned long long)memo_hits);
+        }
+    }
 
     // ---- 3. store state ----
     if (err) { phase = PH_ERROR; status = err; }
@@ -1336,6 +1429,45 @@ __global__ __launch_bounds__(64) void af_move_results_kernel(EngineParams P, int
 // ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
+// Evaluation memo, the writing side: one wave per game, launched after the forward that evaluated this tick's parked leaves.  Reads
+// nothing the tick kernel writes concurrently (same stream, a launch of its own) and the tick kernel never writes the memo, so
+// neither side can see a torn entry.  Inside this launch an entry has one writer: the first wave whose atomicMax of the launch
+// serial on the entry's lock word returns an older serial; the others drop their insert (the position will come by again).
+template <int KW>
+__global__ __launch_bounds__(64) void af_memo_insert_kernel(EngineParams P, const float* __restrict__ policy, const float* __restrict__ value) {
+    constexpr int CP = 64 * KW, MK = 4 * KW;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!rfli(P.pending[g])) return;
+    u64 lm[KW], lt[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        lm[k] = rfl64(P.leaf[(size_t)g * 2 * KW + k]);
+        lt[k] = rfl64(P.leaf[(size_t)g * 2 * KW + KW + k]);
+    }
+    if (bb_count<KW>(lm) + bb_count<KW>(lt) > P.memo_max_stones) return;
+    const int last = rfli(P.leaf_last[g]);
+    const uint32_t bucket = memo_bucket<KW>(P, lm, lt, last);
+    uint32_t empty_ways;
+    if (memo_probe<KW>(P, bucket, lm, lt, last, lane, &empty_ways) >= 0) return;            // another game brought it earlier
+    const u64 serial = rfl64(P.memo_stats[MEMO_SERIAL]);
+    // way: an entry never written, else one chosen by hash and launch (every entry of a full bucket is replaced in turn)
+    const int way = empty_ways ? __builtin_ctz(empty_ways) : (int)((key_hash<KW>(lm, lt) >> 24) + (uint32_t)serial) & 3;
+    const size_t e = (size_t)bucket * 4 + way;
+    int own = 0;
+    if (lane == 0) own = atomicMax(reinterpret_cast<unsigned long long*>(&P.memo_lock[e]), (unsigned long long)serial) < serial ? 1 : 0;
+    if (!rfli(own)) return;
+    if (lane < MK) P.memo_key[e * MK + lane] = memo_word<KW>(lm, lt, last, lane);
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int c = lane + 64 * k;
+        P.memo_pv[e * CP + c] = c < P.C ? policy[(size_t)g * P.C + c] : (c == P.C ? value[g] : 0.0f);
+    }
+    if (lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&P.memo_stats[MEMO_INSERTS]), 1ull);
+        if (!empty_ways) atomicAdd(reinterpret_cast<unsigned long long*>(&P.memo_stats[MEMO_REPLACED]), 1ull);
+    }
+}
+
 struct af_engine {
     EngineParams P;
     int device;
@@ -1348,6 +1480,8 @@ struct af_engine {
     int64_t pack_cap = 0;
     std::vector<int32_t> pack_host;
     std::vector<u64> h_ct;
+    bool memo = false;                // af_engine_memo_enable
+    size_t memo_entries = 0;
 };
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[af_engine] %s failed: %s\n", #x, hipGetErrorString(e_)); return AF_ERR_HIP; } } while (0)
@@ -1463,11 +1597,62 @@ int32_t af_engine_max_plies(const af_engine* e) { return e->P.max_ply; }
 int af_engine_tick(af_engine* e, void* stream, const float* policy_dev, const float* value_dev, float* planes_dev) {
     if (!e || !planes_dev) return AF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-#define AF_TICK(KW_, W_) hipLaunchKernelGGL((af_tick_kernel<KW_, W_>), dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev, planes_dev)
-    if (e->KW == 2) { if (e->P.w64) AF_TICK(2, true); else AF_TICK(2, false); }
-    else { if (e->P.w64) AF_TICK(4, true); else AF_TICK(4, false); }
+#define AF_TICK(KW_, W_, M_) hipLaunchKernelGGL((af_tick_kernel<KW_, W_, M_>), dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev, planes_dev)
+    if (e->memo) {
+        if (e->KW == 2) { if (e->P.w64) AF_TICK(2, true, true); else AF_TICK(2, false, true); }
+        else { if (e->P.w64) AF_TICK(4, true, true); else AF_TICK(4, false, true); }
+    } else {
+        if (e->KW == 2) { if (e->P.w64) AF_TICK(2, true, false); else AF_TICK(2, false, false); }
+        else { if (e->P.w64) AF_TICK(4, true, false); else AF_TICK(4, false, false); }
+    }
 #undef AF_TICK
     HIP_OK(hipGetLastError());
+    return AF_OK;
+}
+
+int af_engine_memo_enable(af_engine* e, int32_t log2_buckets, int32_t max_stones) {
+    if (!e || e->memo || log2_buckets < 4 || log2_buckets > 28 || max_stones < 0) return AF_ERR_ARG;
+    HIP_OK(hipSetDevice(e->device));
+    EngineParams& P = e->P;
+    const size_t NE = (size_t)4 << log2_buckets, CP = 64 * (size_t)e->KW, MK = 4 * (size_t)e->KW;
+    int rc = AF_OK;
+    if (rc == AF_OK) rc = dalloc(e, &P.memo_key, NE * MK);
+    if (rc == AF_OK) rc = dalloc(e, &P.memo_pv, NE * CP);
+    if (rc == AF_OK) rc = dalloc(e, &P.memo_lock, NE);
+    if (rc == AF_OK) rc = dalloc(e, &P.memo_stats, (size_t)MEMO_N);
+    if (rc != AF_OK) return rc;
+    P.memo_bucket_mask = (uint32_t)((1ull << log2_buckets) - 1ull);
+    P.memo_max_stones = max_stones;
+    P.memo_budget = P.budget < 6 ? P.budget : 6;      // profiles/r5_31: 5 and 8 give the same moves/s (fewer yields vs a shorter launch)
+    if (const char* b = getenv("AF_MEMO_BUDGET")) { const int v = atoi(b); if (v > 0) P.memo_budget = v; }
+    e->memo_entries = NE;
+    e->memo = true;
+    return AF_OK;
+}
+
+int af_engine_memo_insert(af_engine* e, void* stream, const float* policy_dev, const float* value_dev) {
+    if (!e || !e->memo || !policy_dev || !value_dev) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (e->KW == 2) hipLaunchKernelGGL((af_memo_insert_kernel<2>), dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev);
+    else hipLaunchKernelGGL((af_memo_insert_kernel<4>), dim3(e->P.G), dim3(64), 0, st, e->P, policy_dev, value_dev);
+    HIP_OK(hipGetLastError());
+    return AF_OK;
+}
+
+int af_engine_memo_clear(af_engine* e, void* stream) {
+    if (!e || !e->memo) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // keys only: an all-zero key row is an empty entry; lock words and the serial keep counting
+    HIP_OK(hipMemsetAsync(e->P.memo_key, 0, e->memo_entries * 4 * (size_t)e->KW * 8, st));
+    return AF_OK;
+}
+
+int af_engine_memo_stats(af_engine* e, void* stream, uint64_t* out) {
+    if (!e || !e->memo || !out) return AF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemcpyAsync(out, e->P.memo_stats, (size_t)MEMO_N * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    out[MEMO_N] = (uint64_t)e->memo_entries;
     return AF_OK;
 }
 

@@ -84,6 +84,10 @@ def lib():
         L.af_engine_progress_async.argtypes = [vp, vp, vp]
         L.af_engine_tick_histogram.argtypes = [vp, vp, u64p, C.c_int32]
         L.af_engine_set_tick_budget.argtypes = [vp, C.c_int32]
+        L.af_engine_memo_enable.argtypes = [vp, C.c_int32, C.c_int32]
+        L.af_engine_memo_insert.argtypes = [vp, vp, vp, vp]
+        L.af_engine_memo_clear.argtypes = [vp, vp]
+        L.af_engine_memo_stats.argtypes = [vp, vp, u64p]
         L.af_engine_tree_dump.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
         L.af_engine_load_tree.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
         L.af_state_to_key.argtypes = [C.c_char_p, C.c_int32, u64p]
@@ -167,7 +171,7 @@ class Engine:
     def params_key(self):
         """Everything set_training / set_simulations / set_tick_budget can change: part of the key of any captured graph."""
         p = self._params
-        return (p["training"], p["sims"], p["upper"], p["tick_budget"])
+        return (p["training"], p["sims"], p["upper"], p["tick_budget"], p.get("memo"))
 
     def set_training(self, training):
         _check(lib().af_engine_set_training(self._h, int(training)), "af_engine_set_training")
@@ -224,6 +228,30 @@ class Engine:
         _check(lib().af_engine_tick_histogram(self._h, stream, _p(out, C.c_uint64), int(reset)), "tick_histogram")
         return dict(selects=out[:64].astype(np.int64), wave_us=out[64:96].astype(np.int64),
                     max_wave_us=float(out[96]) * 0.01)
+
+    # ---- evaluation memo (include/af_engine.h, ABI v5): off unless memo_enable() was called ----
+    def memo_enable(self, log2_buckets=20, max_stones=5):
+        """Share evaluations between the games of this engine: positions with <= max_stones stones, 4 << log2_buckets entries
+        (584 B each at 11x11, 1160 B at 15x15).  Trees stay bit-identical; a launch's parameters change (params_key)."""
+        _check(lib().af_engine_memo_enable(self._h, int(log2_buckets), int(max_stones)), "af_engine_memo_enable")
+        self._params["memo"] = (int(log2_buckets), int(max_stones))
+
+    @property
+    def memo(self):
+        return self._params.get("memo")
+
+    def memo_insert(self, policy_ptr, value_ptr, stream=None):
+        """After the forward of a tick, same stream: remember the evaluations of the leaves the last tick() parked."""
+        _check(lib().af_engine_memo_insert(self._h, stream, policy_ptr, value_ptr), "af_engine_memo_insert")
+
+    def memo_clear(self, stream=None):
+        """The evaluator's weights changed: forget everything (stream-ordered)."""
+        _check(lib().af_engine_memo_clear(self._h, stream), "af_engine_memo_clear")
+
+    def memo_stats(self, stream=None):
+        out = np.zeros(6, np.uint64)
+        _check(lib().af_engine_memo_stats(self._h, stream, _p(out, C.c_uint64)), "af_engine_memo_stats")
+        return {k: int(v) for k, v in zip(("launches", "probes", "hits", "inserts", "replaced", "entries"), out)}
 
     def set_tick_budget(self, selects_per_launch):
         _check(lib().af_engine_set_tick_budget(self._h, int(selects_per_launch)), "af_engine_set_tick_budget")
@@ -337,7 +365,7 @@ class SelfPlayEngine:
     """
 
     def __init__(self, cfg, num_games, pv_device, device=0, seed=0, first_game_id=0, training=True, node_cap=0,
-                 value_f64=False, weights_version=None):
+                 value_f64=False, weights_version=None, eval_memo=None):
         import torch
         if not torch.cuda.is_available():
             raise EngineError("SelfPlayEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -358,6 +386,16 @@ class SelfPlayEngine:
         self._weights_version = self._resolve_weights_version(weights_version)
         if hasattr(pv_device, "bind_outputs"):       # the HIP net writes into our tensors: no copy per tick
             pv_device.bind_outputs(self.policy, self.value)
+        # eval_memo=dict(log2_buckets=.., max_stones=..) (or True for the defaults): evaluations are shared between the games
+        # (Engine.memo_enable).  The stored bits belong to one set of weights, so the memo needs the same version source as
+        # the graph loop and is cleared, stream-ordered, in front of the first tick that sees a new version.
+        self._memo_version = None
+        if eval_memo:
+            if self._weights_version is None:
+                raise EngineError("eval_memo: the evaluator exposes no weights_version (the memo could not tell when to forget); "
+                                  "pass SelfPlayEngine(..., weights_version=lambda: net.version)")
+            self.engine.memo_enable(**({} if eval_memo is True else dict(eval_memo)))
+            self._memo_version = self._weights_version()
         self.ticks = 0
         self._boxes = {}
         self._graph = None
@@ -368,12 +406,20 @@ class SelfPlayEngine:
         """One simulation step for every game: tree kernel -> leaf batch -> net."""
         torch = self.torch
         stream = torch.cuda.current_stream(self.dev).cuda_stream
+        memo = self.engine.memo is not None
+        if memo:
+            ver = self._weights_version()
+            if ver != self._memo_version:            # new weights: every leaf parked from this tick on is evaluated by them
+                self.engine.memo_clear(stream)
+                self._memo_version = ver
         self.engine.tick(self.policy.data_ptr(), self.value.data_ptr(), self.planes.data_ptr(), stream)
         p, v = self.pv_device(self.planes)
         if p.data_ptr() != self.policy.data_ptr():
             self.policy.copy_(p.reshape(self.G, self.C))
         if v.data_ptr() != self.value.data_ptr():
             self.value.copy_(v.reshape(self.G))
+        if memo:
+            self.engine.memo_insert(self.policy.data_ptr(), self.value.data_ptr(), stream)
         self.ticks += 1
 
     def run_ticks(self, n, check_every=0):

@@ -272,6 +272,8 @@ EXTRA_LEGS = {
     "config4": ["--board", "15", "--sims", "800", "--upper", "942", "--games", "4096", "--age-plies", "24", "--warmup", "3", "--steps", "6"],
     # BASELINE.json configs[4]: 11x11, 8-block x 128 residual net in bf16, 8192 games
     "config5": ["--net", "deep-bf16", "--games", "8192", "--age-plies", "12", "--warmup", "3", "--steps", "8"],
+    # the headline workload once more with the evaluation memo on (same trees, fewer forwards): reported beside the headline, never as it
+    "config2_memo": ["--eval-memo", "22:5", "--warmup", "5", "--steps", "20"],
 }
 
 
@@ -306,6 +308,8 @@ def extra_config_legs(timeout_s=240):
                      name + "_steps": j["steps"], name + "_ms_per_step": j["ms_per_step"], name + "_wall_s": time.time() - t0})
         if "mfma_issued_frac" in rf:
             flat[name + "_mfma_issued_frac"] = rf["mfma_issued_frac"]
+        if j["config"].get("eval_memo"):
+            flat[name + "_hits_per_simulation"] = j["config"]["eval_memo"]["hits_per_simulation"]
         full[name] = {"cmd": " ".join(["python", "bench.py"] + cmd[2:]), "metric": j["metric"], "value": j["value"], "dtype": j["dtype"],
                       "config": j["config"], "roofline": {k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "ms_per_launch")},
                       "time_split": j["time_split"]}
@@ -410,6 +414,9 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short steady-state legs of BASELINE configs[3] (15x15, 800 sims) and configs[4] (8-block bf16 net, "
                          "8192 games) that the default N=1 run appends as flat keys config4_* / config5_*")
+    ap.add_argument("--eval-memo", default="", metavar="LOG2_BUCKETS:MAX_STONES",
+                    help="share evaluations between the games of a rank (include/af_engine.h ABI v5; e.g. 22:5).  Off for the headline: "
+                         "the default run measures it in a leg of its own (config2_memo_*)")
     ap.add_argument("--pipe-values", action="store_true",
                     help="W / Q in fp64: the arithmetic of main.py's pipe-fed workers (networkAPI.py:72); default = the pv_fn path")
     ap.add_argument("--net", default="hip", choices=["hip", "torch", "deep-bf16", "deep-bf16-torch"],
@@ -469,7 +476,11 @@ def main():
         pv = deep.select_backend("torch" if args.net.endswith("torch") else "hip", G)   # "hip" raises without libaf_tower.so
     else:
         pv = net.select_backend(args.net)
-    sp = SelfPlayEngine(cfg, G, pv, device=local, seed=args.seed, first_game_id=rank * G, value_f64=args.pipe_values)
+    memo = None
+    if args.eval_memo:
+        lb, ms = (int(x) for x in args.eval_memo.split(":"))
+        memo = dict(log2_buckets=lb, max_stones=ms)
+    sp = SelfPlayEngine(cfg, G, pv, device=local, seed=args.seed, first_game_id=rank * G, value_f64=args.pipe_values, eval_memo=memo)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     ev_tick, ev_net = [], []
@@ -487,6 +498,8 @@ def main():
                 sp.policy.copy_(p)
                 sp.value.copy_(v)
             e2.record()
+            if memo:
+                sp.engine.memo_insert(sp.policy.data_ptr(), sp.value.data_ptr(), stream)
             ev_tick.append((e0, e1))
             ev_net.append((e1, e2))
             sp.ticks += 1
@@ -589,6 +602,7 @@ def main():
     barrier()
     target = sp.progress()[0]
     ct0 = sp.counters()
+    ms0 = sp.engine.memo_stats(stream) if memo else None
     p0 = sp.progress()[0]
     sp.engine.tick_histogram(stream, reset=True)
     timing["on"] = True
@@ -605,6 +619,14 @@ def main():
     timing["on"] = False
     ticks_timed = sp.ticks - ticks0
     ct1 = sp.counters()
+    memo_report = None                               # rank 0's engine, timed region only
+    if memo:
+        ms1 = sp.engine.memo_stats(stream)
+        dm = {k: ms1[k] - ms0[k] for k in ("launches", "probes", "hits", "inserts", "replaced")}
+        memo_report = dict(memo, entries=ms1["entries"], bytes=ms1["entries"] * (584 if cfg.board_size ** 2 <= 128 else 1160), **dm,
+                           hits_per_simulation=dm["hits"] / max(1, ct1["sims"] - ct0["sims"]),
+                           note="evaluations shared between the games of a rank: a leaf another game had evaluated before is expanded "
+                                "at once from the stored bits; trees are bit-identical to the run without it (tests/test_gpu_eval_memo.py)")
     hist = sp.engine.tick_histogram(stream)
     plies = sp.progress()[0] - p0
 
@@ -731,6 +753,7 @@ def main():
                        "selects_per_sim": d["selects"] / max(1, d["sims"]),
                        "terminal_frac": d["terminals"] / max(1, d["sims"]),
                        "episodes_gathered": gathered_in_region, "episodes_finished_in_timed_region": int(eps_all.item()),
+                       "eval_memo": memo_report,
                        # self-verification of the N>1 line: the process group as it really was, and rank 0's receipt of every
                        # episode any rank finished since its engine was created (after an untimed drain of what was still queued)
                        "ranks_seen": ranks_seen, "backend": backend if world > 1 else "none (single process)",

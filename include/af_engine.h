@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 4
+#define AF_ABI_VERSION 5
 
 /* engine modes */
 #define AF_MODE_SELFPLAY 0   /* Player.run loop on device: games restart forever (main.py:82 gen_data) */
@@ -155,6 +155,23 @@ int af_engine_pop_episodes(af_engine* e, void* stream, int32_t cap, int32_t* met
  * out[9..12] = store-collector runs, node slots it scanned, yields, episode-buffer stalls */
 #define AF_NUM_COUNTERS 13
 int af_engine_counters(af_engine* e, void* stream, uint64_t* out);
+
+/* ABI v5 — evaluation memo (optional, off by default).  The net is a pure function of a leaf's (stones, last move) planes
+ * (utils.py:256-272) and this package's forward is independent of batch slot and batch size to the bit, so a position that ANY
+ * game of the engine has had evaluated before need not wait a tick for the same bits again: with the memo enabled a game that
+ * reaches an unseen position holding at most `max_stones` stones looks it up (4-way buckets, exact key = both bitboards + last
+ * move) and on a hit expands it at once (player.py:186-202) and goes on with its next simulation inside the same launch.  Every
+ * game still owns its tree and every tree is bit-identical to the run without the memo; only the number of ticks differs.
+ *   af_engine_memo_enable  allocates 4 << log2_buckets entries of (32 KW + 256 KW + 8) bytes; once per engine.
+ *   af_engine_memo_insert  enqueue after the forward of a tick (same stream): stores the evaluations of the leaves parked by the
+ *                          last af_engine_tick, read from the same policy/value buffers the next tick will consume.
+ *   af_engine_memo_clear   enqueue whenever the evaluator's weights change (stream-ordered): the stored bits are the old net's.
+ *   af_engine_memo_stats   out[0..5] = launches, probes, hits, inserts, replacements, entries allocated (synchronises). */
+#define AF_MEMO_STATS 6
+int af_engine_memo_enable(af_engine* e, int32_t log2_buckets, int32_t max_stones);
+int af_engine_memo_insert(af_engine* e, void* stream, const float* policy_dev, const float* value_dev);
+int af_engine_memo_clear(af_engine* e, void* stream);
+int af_engine_memo_stats(af_engine* e, void* stream, uint64_t* out);
 
 /* launch-shape evidence, accumulated over all games and launches since the last reset:
  * out[0..63] = histogram of selects per game and launch (63 = 63 or more), out[64..95] = histogram of

@@ -1,0 +1,134 @@
+"""The evaluation memo (include/af_engine.h ABI v5): games of one engine share the net's evaluations of positions with few
+stones.  The reference gives every worker its own tree (genData/player.py:38) and asks the net for every unseen leaf
+(player.py:186-197); the memo only answers such a request at once when ANY game has asked it before — the answer is the same
+bits (the forward is batch-slot and batch-size independent, tests/test_gpu_net.py), so every tree, every visit count and every
+recorded episode must be what the run without the memo produces: compared here bit for bit, and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import pseudonet
+from conftest import GOLDEN, make_cfg
+from test_gpu_graph_loop import _drain, _same_episodes
+
+pytestmark = pytest.mark.gpu
+W = os.path.join(GOLDEN, "alphaFive-6960.weights.npz")
+
+
+def _run_until(sp, plies, graph=False, chunk=64, episodes=0):
+    got = []
+    while sp.progress()[0] < plies or sp.progress()[1] < episodes:
+        if graph:
+            for _ in range(chunk // 16):
+                sp.run_ticks_graph(16)
+        else:
+            sp.run_ticks(chunk)
+        sp.check()
+        got += _drain(sp)
+    sp.check()
+    got += _drain(sp)
+    return got
+
+
+def _common(a, b):
+    by = {(e["game"], e["seq"]): e for e in b}
+    ca = [e for e in a if (e["game"], e["seq"]) in by]
+    return ca, [by[(e["game"], e["seq"])] for e in ca]
+
+
+def test_memo_run_equals_plain_run_and_the_oracle_on_the_pseudo_net():
+    from alphafive_amd.engine import SelfPlayEngine, EngineError
+    cfg = make_cfg(board_size=6, goal=4, simulation_per_step=60, upper_simulation_per_step=80)
+    salt, peak, seed, G = 11, 16384, 3, 64
+    pv = lambda x: pseudonet.pseudonet_torch(x, salt, peak)                  # noqa: E731
+    with pytest.raises(EngineError, match="weights_version"):                # no way to tell when to forget: refused
+        SelfPlayEngine(cfg, 4, pv, device=0, seed=seed, eval_memo=True)
+    a = SelfPlayEngine(cfg, G, pv, device=0, seed=seed, weights_version=0, eval_memo=dict(log2_buckets=8, max_stones=6))
+    b = SelfPlayEngine(cfg, G, pv, device=0, seed=seed)
+    got_a = _run_until(a, 40 * G)
+    got_b = _run_until(b, 40 * G)
+    st = a.engine.memo_stats()
+    assert st["entries"] == 4 << 8 and st["hits"] > 1000 and st["replaced"] > 0 and st["probes"] >= st["hits"]
+    assert a.ticks < b.ticks                                                  # the same plies in fewer launches
+    ca, cb = _common(got_a, got_b)
+    assert len(ca) >= G
+    _same_episodes(ca, cb)
+    ct_a, ct_b = a.counters(), b.counters()
+    assert ct_a["expands"] > 0 and st["hits"] < ct_a["expands"]
+    for e in [x for x in got_a if x["seq"] <= 1][:10]:
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=seed, game_id=e["game"],
+                                  pseudo_salt=salt, pseudo_peak=peak)
+        for _ in range(e["seq"] + 1):
+            orec, extra = orc.run()
+        assert e["T"] == len(orec) and (e["visits"] == extra["visits"]).all() and (e["actions"] == extra["actions"]).all()
+    a.close()
+    b.close()
+
+
+def test_memo_with_the_hand_written_net_graph_loop_and_15x15():
+    """alphaFive-6960 through af_conv_f16s, eager and inside the HIP graph (the insert kernel is captured with the forward); a
+    small table so that entries are replaced all the time; 15x15 keys (4 words per bitboard) on the random-init net."""
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.network import ResNet
+    for S, sims, G, plies in ((11, 40, 128, 24), (15, 24, 64, 10)):
+        cfg = make_cfg(board_size=S, simulation_per_step=sims, upper_simulation_per_step=sims + 20)
+        nets = [ResNet(S, device="cuda", seed=0) for _ in range(3)]
+        if S == 11:
+            for nt in nets:
+                nt.load_npz(W)
+        memo = dict(log2_buckets=7, max_stones=7)
+        a = SelfPlayEngine(cfg, G, nets[0].select_backend("hip"), device=0, seed=21, eval_memo=memo)
+        g = SelfPlayEngine(cfg, G, nets[1].select_backend("hip"), device=0, seed=21, eval_memo=memo)
+        b = SelfPlayEngine(cfg, G, nets[2].select_backend("hip"), device=0, seed=21)
+        got_a, got_g, got_b = (_run_until(sp, plies * G, graph=sp is g, episodes=G) for sp in (a, g, b))
+        assert g._graph is not None and g._graph[0][1][-1] == (7, 7)
+        for sp in (a, g):
+            st = sp.engine.memo_stats()
+            assert st["hits"] > 200 and st["replaced"] > 0, st
+        assert a.ticks <= b.ticks
+        for got in (got_a, got_g):
+            ca, cb = _common(got, got_b)
+            assert len(ca) >= G // 4
+            _same_episodes(ca, cb)
+        for sp in (a, g, b):
+            sp.close()
+
+
+def test_new_weights_empty_the_memo():
+    """Episodes that start after a weight change must be the new net's from their first simulation on: the memo is full of the
+    old net's evaluations of exactly the opening positions such an episode asks for first."""
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.network import ResNet, random_variables
+    cfg = make_cfg(simulation_per_step=24, upper_simulation_per_step=30)
+    G = 48
+    na, nb = ResNet(11, device="cuda"), ResNet(11, device="cuda")
+    na.load_npz(W)
+    nb.set_variables(random_variables(11, seed=5))
+    a = SelfPlayEngine(cfg, G, na.select_backend("hip"), device=0, seed=2, eval_memo=dict(log2_buckets=12, max_stones=8))
+    b = SelfPlayEngine(cfg, G, nb.select_backend("hip"), device=0, seed=2)
+    old = _run_until(a, 30 * G)                                        # W1: games are somewhere in their 2nd .. 3rd episode
+    assert a.engine.memo_stats()["hits"] > 500
+    na.set_variables(random_variables(11, seed=5))
+    started = {gm: 0 for gm in range(G)}                               # the episode every game was in at the switch:
+    for e in old:                                                      # (everything finished has been drained)
+        started[e["game"]] = max(started[e["game"]], e["seq"] + 1)
+    new, after = [], []
+    while len(after) < G // 2:
+        new += _run_until(a, a.progress()[0] + 40 * G)
+        after = [e for e in new if e["seq"] > started[e["game"]]]      # begun after the switch: all of it is the new net's
+        assert a.ticks < 400000
+    need = max(e["seq"] for e in after)
+    got_b = []
+    while True:
+        got_b += _run_until(b, b.progress()[0] + 40 * G)
+        have = {(e["game"], e["seq"]) for e in got_b}
+        if all((e["game"], e["seq"]) in have for e in after):
+            break
+        assert b.ticks < 400000 and need < 50
+    ca, cb = _common(after, got_b)
+    assert len(ca) == len(after)
+    _same_episodes(ca, cb)
+    a.close()
+    b.close()
