@@ -166,6 +166,7 @@ int af_engine_counters(af_engine* e, void* stream, uint64_t* out);
  *   af_engine_memo_insert  enqueue after the forward of a tick (same stream): stores the evaluations of the leaves parked by the
  *                          last af_engine_tick, read from the same policy/value buffers the next tick will consume.
  *   af_engine_memo_clear   enqueue whenever the evaluator's weights change (stream-ordered): the stored bits are the old net's.
+ *                          (A memset of the key rows: meant for weights that are synchronised in intervals, not at every step.)
  *   af_engine_memo_stats   out[0..5] = launches, probes, hits, inserts, replacements, entries allocated (synchronises). */
 #define AF_MEMO_STATS 6
 int af_engine_memo_enable(af_engine* e, int32_t log2_buckets, int32_t max_stones);
