@@ -132,3 +132,26 @@ def test_new_weights_empty_the_memo():
     _same_episodes(ca, cb)
     a.close()
     b.close()
+
+
+def test_memo_at_the_metric_settings_complete_episodes_equal_the_oracle():
+    """configs[1]'s search settings (11x11, 500 sims/move, cap 642) on 1024 games with the memo on: every game finishes an
+    episode (terminal simulations, store collection, restarts, hit streaks at the start of every episode), sampled games'
+    complete episodes bit for bit vs the oracle, and the bookkeeping invariants with the memo's share of the expansions."""
+    from alphafive_amd.engine import SelfPlayEngine
+    from test_gpu_fullsize import SALT, PEAK, SEED, _assert_episode_equals_oracle, _play_until_every_game_finished
+    cfg = make_cfg(simulation_per_step=500, upper_simulation_per_step=642)
+    G = 1024
+    sp = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, SALT, PEAK), device=0, seed=SEED, weights_version=0,
+                        eval_memo=dict(log2_buckets=14, max_stones=5))
+    got = _play_until_every_game_finished(sp, G, max_rounds=200)
+    ct, st = sp.counters(), sp.engine.memo_stats()
+    sp.close()
+    assert len(got) == G
+    assert ct["sims"] == ct["expands"] + ct["terminals"] and ct["stalls"] == 0
+    assert 0.03 * ct["expands"] < st["hits"] < 0.5 * ct["expands"] and st["inserts"] > 0     # a real share, far from all
+    for g in (0, 1, 333, 777, G - 1):
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
+                                  pseudo_salt=SALT, pseudo_peak=PEAK)
+        for raw in got[g][:2 if g == 0 else 1]:
+            _assert_episode_equals_oracle(raw, orc, 11, cfg.gamma)
