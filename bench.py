@@ -161,6 +161,61 @@ def _cpu_worker(args):
     print(json.dumps({"plies": r["plies"], "dt": r["dt"], "complete": r["complete"]}), flush=True)
 
 
+class PowerSampler(object):
+    """The board's own power sensor and shader clock (amdgpu hwmon under the device's PCI node, read at ~10 Hz by a thread of this
+    process) over the timed region: DESIGN's "the forward sits at the power wall" as a sensor reading on the bench line instead of
+    an inference from counters.  Reads sysfs only; a box without the sensor gives roofline.power = null."""
+
+    def __init__(self, props):
+        import glob
+        self.rows, self._stop, self._th, self.paths = [], None, None, None
+        try:
+            bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+            hw = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf))
+            if hw:
+                pw = [q for q in (hw[0] + "/power1_average", hw[0] + "/power1_input") if os.path.exists(q)]
+                if pw:
+                    self.paths = {"power": pw[0], "cap": hw[0] + "/power1_cap", "sclk": hw[0] + "/freq1_input"}
+        except Exception:
+            self.paths = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        if self.paths is None:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                self.rows.append((self._read(self.paths["power"]), self._read(self.paths["sclk"])))
+                self._stop.wait(0.1)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self._th is None:
+            return None
+        self._stop.set()
+        self._th.join()
+        pw = sorted(r[0] / 1e6 for r in self.rows if r[0] is not None)
+        ck = [r[1] / 1e9 for r in self.rows if r[1] is not None]
+        cap = self._read(self.paths["cap"])
+        if not pw:
+            return None
+        return {"cap_w": cap / 1e6 if cap else None, "mean_w": sum(pw) / len(pw), "p50_w": pw[len(pw) // 2], "max_w": pw[-1],
+                "frac_of_cap": (sum(pw) / len(pw)) / (cap / 1e6) if cap else None,
+                "sclk_ghz_mean": sum(ck) / len(ck) if ck else None, "samples": len(pw),
+                "source": "amdgpu hwmon %s + freq1_input, 10 Hz over the timed region (rank 0's device)" % os.path.basename(self.paths["power"])}
+
+
 def copy_bandwidth_gbs(dev, mib=1024, reps=10):
     """Measured device copy bandwidth (read + write bytes / time): the achievable-HBM denominator SURVEY §8d asks for."""
     import torch
@@ -608,6 +663,9 @@ def main():
     timing["on"] = True
     ticks0 = sp.ticks
     gathered_at_t0 = gathered["episodes"]
+    power = PowerSampler(torch.cuda.get_device_properties(dev)) if rank == 0 else None
+    if power is not None:
+        power.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         target += G
@@ -615,6 +673,7 @@ def main():
     collect(last=True)                                # the last steps' episodes
     barrier()
     elapsed = time.perf_counter() - t0
+    power_report = power.stop() if power is not None else None
     gathered_in_region = gathered["episodes"] - gathered_at_t0
     timing["on"] = False
     ticks_timed = sp.ticks - ticks0
@@ -804,6 +863,7 @@ def main():
             out["roofline"]["hbm_algorithmic_bytes_per_launch"] = hb
             out["roofline"]["hbm_algorithmic_gbs"] = hb / (net_ms * 1e-3) / 1e9
             out["roofline"]["hbm_frac_of_peak"] = hb / (net_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+        out["roofline"]["power"] = power_report                 # the board's sensor over the timed region (None without one)
         if pmc is not None and "sustained_clock_ghz" in pmc:
             # what DESIGN argues from the counters, reproducible from this line alone: the chip is power-bound under this load, so the
             # MFMA pipe's ceiling is the clock it sustains, not the nominal 2.4 GHz the 2.5 PFLOP/s peak is quoted at
