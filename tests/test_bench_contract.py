@@ -109,3 +109,15 @@ def test_plain_python_gpus_n_spawns_ranks_and_a_failing_rank_ends_the_job():
     assert "launch with torch.distributed.run" not in err
     assert err.count("needs a HIP device") >= 1                  # at least the first rank to fail got that far; the rest were stopped
     assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_power_sampler_without_a_sensor_reports_nothing():
+    """bench.PowerSampler reads the amdgpu hwmon node of the device's PCI address; a box without one (this container) must give
+    roofline.power = None, never an exception inside the timed region."""
+    import types
+    import bench
+    ps = bench.PowerSampler(types.SimpleNamespace(pci_domain_id=0xffff, pci_bus_id=0xfe, pci_device_id=0x1f))
+    assert ps.paths is None
+    ps.start()
+    assert ps.stop() is None
+    assert bench.PowerSampler(object()).stop() is None              # a properties object without the PCI fields
