@@ -42,6 +42,8 @@ def test_bench_line_carries_the_contract():
     assert 1.5 < r["sustained_clock_ghz"] < 2.45 and r["nominal_clock_ghz"] == 2.4 and 0.3 < r["mfma_busy"] < 0.9
     assert abs(r["sustained_peak_tflops"] - r["peak"] * r["sustained_clock_ghz"] / 2.4) < 1e-6 * r["peak"]
     assert abs(r["frac_of_sustained_peak"] - r["achieved"] / r["sustained_peak_tflops"]) < 1e-9
+    pw = r["power"]                                                            # the board's sensor over the timed region
+    assert pw is None or (0.5 < pw["frac_of_cap"] <= 1.02 and 1.0 < pw["sclk_ghz_mean"] < 2.5 and pw["samples"] >= 20)
     assert abs(r["mfma_issued_frac_of_sustained_peak"] - r["mfma_issued_tflops"] / r["sustained_peak_tflops"]) < 1e-9
     pk = r["per_kernel"]
     assert len(pk) >= 8 and all(set(("kernel", "us", "ghz", "mfma_busy", "mfma_issued_tflops", "hbm_mb")) <= set(e) for e in pk)
