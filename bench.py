@@ -332,13 +332,21 @@ EXTRA_LEGS = {
 }
 
 
-def extra_config_legs(timeout_s=240):
+PROCESS_T0 = time.time()
+
+
+def extra_config_legs(timeout_s=240, wall_budget_s=600.0):
     """Short steady-state legs of the two other single-GPU configurations BASELINE.json names, run as child processes of this
     same file after the default workload (so the driver's one `python bench.py` sees them): flat keys configN_* on the JSON
     line plus the children's own lines under "extra_configs".  A leg that fails or times out is reported as an error string."""
     import subprocess
     flat, full = {}, {}
     for name, leg in EXTRA_LEGS.items():
+        # the whole default run is meant to finish within minutes also on a box that pages the image in for the first time (every
+        # child start then costs tens of seconds): a leg that would start past the budget is skipped and says so
+        if time.time() - PROCESS_T0 > wall_budget_s - 60.0:
+            flat[name + "_error"] = "skipped: %.0f s of the run's %.0f-s wall budget were used before this leg" % (time.time() - PROCESS_T0, wall_budget_s)
+            continue
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-pmc", "--no-extra-configs"] + leg
         t0 = time.time()
         try:
