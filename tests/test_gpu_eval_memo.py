@@ -155,3 +155,21 @@ def test_memo_at_the_metric_settings_complete_episodes_equal_the_oracle():
                                   pseudo_salt=SALT, pseudo_peak=PEAK)
         for raw in got[g][:2 if g == 0 else 1]:
             _assert_episode_equals_oracle(raw, orc, 11, cfg.gamma)
+
+
+def test_bench_reports_the_memo_leg_keys():
+    """`bench.py --eval-memo L:K` (what the default run starts as its config2_memo leg): the line says what the memo did in the timed
+    region of rank 0's engine, and the headline keys keep their meaning."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--games", "512", "--steps", "2", "--warmup", "0",
+                        "--eval-memo", "12:5", "--no-cpu-baseline", "--no-pmc", "--no-extra-configs"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    m = d["config"]["eval_memo"]
+    assert m["log2_buckets"] == 12 and m["max_stones"] == 5 and m["entries"] == 4 << 12
+    assert m["probes"] >= m["hits"] > 0 and m["inserts"] > 0 and 0 < m["hits_per_simulation"] < 1
+    assert d["unit"] == "moves/s" and d["config"]["games_per_gpu"] == 512 and "power" in d["roofline"]
