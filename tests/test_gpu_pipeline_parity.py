@@ -1,0 +1,193 @@
+"""The pipeline bench.py times, held to the oracle: the batched SelfPlayEngine + the hand-written
+af_conv_f16s net + the HIP-graph loop (run_ticks_graph), with and without the evaluation memo, at BASELINE's own search
+settings (11x11 500 / 642 with alphaFive-6960; 15x15 800 / 942) — not engine + pseudo-net, not single-game Player + real net,
+but the product of the two.
+
+Reference: genData/player.py:53-82 (run), :128-147 (get_action), :186-202 (evaluate_and_expand: one pv_fn call per unseen leaf).
+
+The oracle players (oracle/af_oracle.c, one per sampled game, PHILOX streams keyed by the game id like the engine's) get their
+evaluations from a SECOND handle of the same kernels.  A leaf's evaluation does not depend on its batch slot or on the batch size
+(tests/test_gpu_net.py: test_hip_net_ragged_batches_and_board_sizes, test_alternate_conv_paths_agree_with_fp64's permutation
+check), so the K oracle players run in K host threads and their pending leaves are evaluated together (batch <= K instead of K
+batch-1 calls: K times fewer device round trips); every 97th batch is re-evaluated slot by slot at batch 1 and must be the same
+bits, so the independence the shortcut stands on is asserted on the very leaves of this run."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, make_cfg
+from test_gpu_fullsize import _assert_episode_equals_oracle
+
+pytestmark = pytest.mark.gpu
+W = os.path.join(GOLDEN, "alphaFive-6960.weights.npz")
+SEED = 1234
+
+
+class _Lockstep:
+    """K oracle threads -> one batched evaluator call per round.  eval(slot, planes) blocks until every live thread has a
+    leaf pending (or has retired), then the last arrival evaluates the batch and wakes the others."""
+
+    def __init__(self, pv_batch, pv_single, K, S):
+        self.pv_batch, self.pv_single, self.S = pv_batch, pv_single, S
+        self.cond = threading.Condition()
+        self.live, self.pending, self.results, self.gen = K, {}, {}, 0
+        self.rounds, self.evals, self.cross_checked, self.error = 0, 0, 0, None
+
+    def _flush(self):
+        import torch
+        slots = sorted(self.pending)
+        x = np.concatenate([self.pending[s] for s in slots]).astype(np.float32)
+        xt = torch.from_numpy(x).cuda()
+        p, v = self.pv_batch(xt)
+        p, v = p.cpu().numpy().copy(), v.cpu().numpy().copy()
+        if self.rounds % 97 == 0:                    # batch-slot / batch-size independence on this run's own leaves
+            for i in range(len(slots)):
+                p1, v1 = self.pv_single(xt[i:i + 1].contiguous())
+                if not ((p1.cpu().numpy()[0] == p[i]).all() and float(v1.cpu().numpy()[0]) == float(v[i])):
+                    self.error = "batch-%d slot %d differs from its batch-1 evaluation (round %d)" % (len(slots), i, self.rounds)
+                self.cross_checked += 1
+        for i, s in enumerate(slots):
+            self.results[s] = (p[i:i + 1], v[i:i + 1])
+        self.pending.clear()
+        self.rounds += 1
+        self.evals += len(slots)
+        self.gen += 1
+        self.cond.notify_all()
+
+    def eval(self, slot, planes):
+        with self.cond:
+            self.pending[slot] = planes
+            if len(self.pending) == self.live:
+                self._flush()
+            else:
+                gen = self.gen
+                while self.gen == gen:
+                    self.cond.wait()
+            return self.results.pop(slot)
+
+    def retire(self):
+        with self.cond:
+            self.live -= 1
+            if self.pending and len(self.pending) == self.live:
+                self._flush()
+
+
+def _drain_into(sp, got, cap=256):
+    while True:
+        raws = sp.pop_raw(cap)
+        for raw in raws:
+            got.setdefault(raw["game"], []).append(raw)
+        if len(raws) < cap:
+            return
+
+
+def _run_pipeline(cfg, G, net, sample, memo, n=16, max_replays=40000):
+    """The bench's loop: run_ticks_graph(n) replays until every sampled game has finished an episode."""
+    from alphafive_amd.engine import SelfPlayEngine
+    sp = SelfPlayEngine(cfg, G, net.select_backend("hip"), device=0, seed=SEED, eval_memo=memo)
+    got, replays = {}, 0
+    while not all(g in got for g in sample):
+        for _ in range(32):
+            sp.run_ticks_graph(n)
+        replays += 32
+        sp.check()
+        _drain_into(sp, got)
+        assert replays < max_replays, "sampled games never finished"
+    assert sp._graph is not None and sp._graph[1] is not None and sp.ticks >= replays * n      # the HIP-graph loop is what ran
+    ct = sp.counters()
+    ms = sp.engine.memo_stats() if memo else None
+    sp.close()
+    return got, ct, ms
+
+
+def _oracle_episodes(cfg, net, games, episodes_per_game):
+    """-> {game: [(records, extra) per episode]} from OraclePlayers fed by a second handle of the net kernels."""
+    S = cfg.board_size
+    pv_batch, pv_single = net.select_backend("hip"), net.select_backend("hip")
+    ls = _Lockstep(pv_batch, pv_single, len(games), S)
+    out, errs = {}, []
+
+    def work(slot, g):
+        try:
+            orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
+                                      pv_fn=lambda x: ls.eval(slot, x))
+            out[g] = [orc.run() for _ in range(episodes_per_game[g])]
+            orc.close()
+        except Exception as e:                       # noqa: BLE001  (a dead thread must not leave the others waiting)
+            errs.append((g, repr(e)))
+        finally:
+            ls.retire()
+
+    threads = [threading.Thread(target=work, args=(i, g)) for i, g in enumerate(games)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    assert ls.error is None, ls.error
+    assert ls.cross_checked > 0
+    return out, ls
+
+
+def _compare(raw, orun, S, gamma):
+    from alphafive_amd.engine import assemble_episode
+    orec, extra = orun
+    tag = "game %d seq %d" % (raw["game"], raw["seq"])
+    assert raw["T"] == len(orec), tag + ": length %d vs %d" % (raw["T"], len(orec))
+    assert (raw["actions"] == extra["actions"]).all(), tag + ": actions"
+    assert (raw["visits"] == extra["visits"]).all(), tag + ": visit counts"
+    assert raw["final_value"] == extra["final_value"], tag + ": final value"
+    rec, _ = assemble_episode(raw, S, gamma)
+    for t, ((s, p, la, v, w), (os_, op, ola, ov, ow)) in enumerate(zip(rec, orec)):
+        assert s == os_ and la == ola and v == ov and w == ow, tag + ": 5-tuple at ply %d" % t
+        assert (p.view(np.uint32) == op.view(np.uint32)).all(), tag + ": policy bits at ply %d" % t
+
+
+def _pipeline_vs_oracle(S, sims, upper, G, sample, memo, weights, seed_net=0):
+    from alphafive_amd.network import ResNet
+    cfg = make_cfg(board_size=S, simulation_per_step=sims, upper_simulation_per_step=upper)
+    net = ResNet(S, device="cuda", seed=seed_net)
+    if weights:
+        net.load_npz(weights)
+    got, ct, ms = _run_pipeline(cfg, G, net, sample, memo)
+    want = {g: min(len(got[g]), 2 if g == sample[0] else 1) for g in sample}     # the first sampled game: its second episode too
+    oruns, ls = _oracle_episodes(cfg, net, list(sample), want)
+    plies = 0
+    for g in sample:
+        assert [e["seq"] for e in got[g]] == list(range(len(got[g])))
+        for raw, orun in zip(got[g][:want[g]], oruns[g]):
+            _compare(raw, orun, S, cfg.gamma)
+            plies += raw["T"]
+    print("pipeline vs oracle: S=%d %d/%d G=%d memo=%s: %d games, %d episodes, %d plies bit-exact; oracle %d evaluations in %d "
+          "batches (%d re-checked at batch 1); engine counters sims=%d terminals=%d%s"
+          % (S, sims, upper, G, memo, len(sample), sum(want.values()), plies, ls.evals, ls.rounds, ls.cross_checked,
+             ct["sims"], ct["terminals"], "" if ms is None else " memo hits=%d" % ms["hits"]))
+    net.close()
+    return ct, ms
+
+
+@pytest.mark.parametrize("memo", [None, dict(log2_buckets=14, max_stones=5)], ids=["plain", "memo"])
+def test_bench_pipeline_11x11_at_the_metric_settings_matches_the_oracle(memo):
+    """BASELINE configs[1]'s search settings and weights on a 256-game engine (the bench runs 4096; a game's tree depends on its
+    id only — shard invariance, tests/test_gpu_fullsize.py): 16 sampled games, complete episodes."""
+    G = 256
+    sample = [0, 1, 2, 17, 31, 64, 77, 100, 127, 128, 150, 199, 200, 222, 254, 255]
+    ct, ms = _pipeline_vs_oracle(11, 500, 642, G, sample, memo, W)
+    assert ct["terminals"] > 0 and ct["stalls"] == 0
+    if memo:
+        assert ms["hits"] > 1000                     # the memo really answered simulations of the compared games' engine
+
+
+@pytest.mark.parametrize("memo", [None, dict(log2_buckets=12, max_stones=5)], ids=["plain", "memo"])
+def test_bench_pipeline_15x15_at_config4_settings_matches_the_oracle(memo):
+    """BASELINE configs[3]'s board and budget (15x15, 800 / 942, KW = 4 tick kernel, Geo<15> net with random-init weights as the
+    bench uses) on a 64-game engine: 8 sampled games, complete episodes."""
+    G = 64
+    sample = [0, 1, 9, 23, 32, 47, 62, 63]
+    ct, ms = _pipeline_vs_oracle(15, 800, 942, G, sample, memo, None, seed_net=15)
+    assert ct["stalls"] == 0
+    if memo:
+        assert ms["hits"] > 100
