@@ -254,7 +254,9 @@ struct F16sArgs {
     float inv_scale2;
     int gx0;              // af_conv_f16s_h15: workgroups (per blockIdx.y) of the half-0 class
     char* stash;          // af_conv_f16s_h15 -> af_corner_f16s: [board][slab of the stream][hi|lo][4 unit rows][pixels 208, 209, 223, 224] units
-    int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses
+    int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses,
+                          // bit 3 (r6) slab loads and activation stores addressed modulo 128 positions (the upper bound of any
+                          // "intermediate tensors never leave the L2s" design: same instruction streams, no HBM behind them)
 };
 
 // The kernel body.  NTW: pixel tiles per wave (4 / PS for a whole pseudo-position); tb: the first pixel tile of this workgroup
@@ -336,7 +338,8 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     // order — long slabs first, so that the epilogue's stores have more time before the next wait on vmcnt — measured
     // 1.58 vs 1.55 ms per forward and moved |dp| from 6.0e-6 to 8.1e-6)
     auto slab_src = [&](int qq, int j) -> const char* {             // (qq: pseudo-position)
-        const int p = (HV == 1 || HSEL >= 0) ? qq : qq / HV;
+        const int p_ = (HV == 1 || HSEL >= 0) ? qq : qq / HV;
+        const int p = (A.abl & 8) ? (p_ & 127) : p_;     // abl bit 3 (profiling): activations addressed modulo 128 positions — every tensor an L2-resident ring
         if (AF_F16S_MAIN_FIRST) return (j < NSM ? A.in + ((size_t)p * NSM + j) * kSlabH : A.in2 + ((size_t)p * NSP + (j - NSM)) * kSlabH) + wsrc;
         return (j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabH : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabH) + wsrc;
     };
@@ -784,7 +787,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
                     for (int r = 0; r < 16; ++r) o[(size_t)r * A.PP] = v[r];
                 }
             } else {
-                char* o = A.out + ((size_t)pos * nso + ctg) * kSlabH + (uint32_t)(2 * kg) * kRowH + (uint32_t)(pix[jj] + G::POFF) * 16u;
+                char* o = A.out + ((size_t)((A.abl & 8) ? (pos & 127) : pos) * nso + ctg) * kSlabH + (uint32_t)(2 * kg) * kRowH + (uint32_t)(pix[jj] + G::POFF) * 16u;
                 // fused block: the tile goes into the LDS activation slab instead (ring-slot layout: [hi|lo][4 unit rows][WINU units])
                 char* og = smem + kGOff + (uint32_t)(2 * kg) * kRowL + (uint32_t)(pix[jj] + G::POFF) * 16u;
 #pragma unroll

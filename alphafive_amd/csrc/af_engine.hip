@@ -77,12 +77,15 @@ struct EngineParams {
     u64* hist;       // HIST_N words, all games
     // evaluation memo (ABI v5, off unless af_engine_memo_enable was called): (position, last move) -> the net's policy and value,
     // shared by all games of the engine.  4-way buckets; a launch only reads it (the tick kernel) or only writes it (af_memo_insert)
-    u64* memo_key;   // [4 * buckets][4 KW]: 2 KW key words, (1 << 32 | last + 1), zeros; an empty entry is all zeros
-    float* memo_pv;  // [4 * buckets][CP]: C policy floats as the net wrote them, the value at [C]
+    u64* memo_key;   // [4 * buckets][4 KW]: 2 KW key words, (epoch << 32 | last + 1), zeros; an entry whose epoch is not the
+                     // launch's memo_epoch is empty (all zeros = never written; older epochs = another weight set's bits)
+    float* memo_pv;  // [4 * buckets][CP]: C policy floats as the net wrote them
+    float* memo_val; // [4 * buckets]: the value (an array of its own: C == CP on a 16x16 board leaves no spare slot in the row)
     u64* memo_lock;  // [4 * buckets]: serial of the launch that last wrote the entry (one writer per entry and launch)
     u64* memo_stats; // MEMO_SERIAL, MEMO_PROBES, MEMO_HITS, MEMO_INSERTS, MEMO_REPLACED
     uint32_t memo_bucket_mask;
     int memo_max_stones;
+    uint32_t memo_epoch; // >= 1; af_engine_memo_clear bumps it (O(1): stale entries simply stop matching)
     int memo_budget;     // selects per launch after which a game that has consumed a memo hit yields (AF_MEMO_BUDGET; default min(budget, 6))
 };
 enum { MEMO_SERIAL = 0, MEMO_PROBES, MEMO_HITS, MEMO_INSERTS, MEMO_REPLACED, MEMO_N };
@@ -398,21 +401,21 @@ __device__ __forceinline__ uint32_t memo_bucket(const EngineParams& P, const u64
     return h & P.memo_bucket_mask;
 }
 template <int KW>
-__device__ __forceinline__ u64 memo_word(const u64* mine, const u64* theirs, int last, int w) {   // word w of the entry's key row
+__device__ __forceinline__ u64 memo_word(const EngineParams& P, const u64* mine, const u64* theirs, int last, int w) {   // word w of the entry's key row
     const u64 kw = key_word<KW>(mine, theirs, w);                                                // (0 for w >= 2 KW)
-    return w == 2 * KW ? ((1ull << 32) | (u64)(uint32_t)(last + 1)) : kw;
+    return w == 2 * KW ? (((u64)P.memo_epoch << 32) | (u64)(uint32_t)(last + 1)) : kw;
 }
-// -> entry index or -1; *empty_ways = bit v set iff way v of the bucket has never been written
+// -> entry index or -1; *empty_ways = bit v set iff way v of the bucket holds nothing of this epoch (never written, or cleared)
 template <int KW>
 __device__ __forceinline__ int memo_probe(const EngineParams& P, uint32_t bucket, const u64* mine, const u64* theirs, int last, int lane,
                                           uint32_t* empty_ways) {
     constexpr int MK = 4 * KW;
     const int w = lane & (MK - 1);
-    const u64 expect = memo_word<KW>(mine, theirs, last, w);
+    const u64 expect = memo_word<KW>(P, mine, theirs, last, w);
     u64 have = expect;
     if (lane < 4 * MK) have = P.memo_key[(size_t)bucket * (4 * MK) + lane];
     const u64 bad = __ballot(have != expect);
-    const u64 blank = __ballot(lane < 4 * MK && w == 2 * KW && have == 0ull);
+    const u64 blank = __ballot(lane < 4 * MK && w == 2 * KW && (uint32_t)(have >> 32) != P.memo_epoch);
     uint32_t em = 0;
     int hit = -1;
 #pragma unroll
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                             for (int k = 0; k < KW; ++k) { lm[k] = cm[k]; lt[k] = ctb[k]; }
                             c_depth = depth; c_slot = slot;
                             c_pol = P.memo_pv + (size_t)me * CP;
-                            c_val = c_pol + C;
+                            c_val = P.memo_val + me;
                             have_eval = true;
                             break;
                         }
@@ -1456,13 +1459,14 @@ __global__ __launch_bounds__(64) void af_memo_insert_kernel(EngineParams P, cons
     int own = 0;
     if (lane == 0) own = atomicMax(reinterpret_cast<unsigned long long*>(&P.memo_lock[e]), (unsigned long long)serial) < serial ? 1 : 0;
     if (!rfli(own)) return;
-    if (lane < MK) P.memo_key[e * MK + lane] = memo_word<KW>(lm, lt, last, lane);
+    if (lane < MK) P.memo_key[e * MK + lane] = memo_word<KW>(P, lm, lt, last, lane);
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const int c = lane + 64 * k;
-        P.memo_pv[e * CP + c] = c < P.C ? policy[(size_t)g * P.C + c] : (c == P.C ? value[g] : 0.0f);
+        P.memo_pv[e * CP + c] = c < P.C ? policy[(size_t)g * P.C + c] : 0.0f;
     }
     if (lane == 0) {
+        P.memo_val[e] = value[g];
         atomicAdd(reinterpret_cast<unsigned long long*>(&P.memo_stats[MEMO_INSERTS]), 1ull);
         if (!empty_ways) atomicAdd(reinterpret_cast<unsigned long long*>(&P.memo_stats[MEMO_REPLACED]), 1ull);
     }
@@ -1481,6 +1485,7 @@ struct af_engine {
     std::vector<int32_t> pack_host;
     std::vector<u64> h_ct;
     bool memo = false;                // af_engine_memo_enable
+    bool memo_budget_fixed = false;   // AF_MEMO_BUDGET given: af_engine_set_tick_budget leaves memo_budget alone
     size_t memo_entries = 0;
 };
 
@@ -1489,7 +1494,13 @@ struct af_engine {
 template <typename T>
 static int dalloc(af_engine* e, T** p, size_t n) {
     void* q = nullptr;
-    HIP_OK(hipMalloc(&q, n * sizeof(T)));
+    if (hipMalloc(&q, n * sizeof(T)) != hipSuccess) {
+        // an allocation that does not fit is the caller's sizing error, not a broken device: report it and take the failure out of
+        // the runtime's sticky last-error slot (the next HIP user of the process — torch — would otherwise trip over it)
+        fprintf(stderr, "[af_engine] hipMalloc of %zu bytes failed (node_cap / num_games too large for the device?)\n", n * sizeof(T));
+        (void)hipGetLastError();
+        return AF_ERR_HIP;
+    }
     HIP_OK(hipMemset(q, 0, n * sizeof(T)));
     e->allocs.push_back(q);
     *p = (T*)q;
@@ -1618,13 +1629,15 @@ int af_engine_memo_enable(af_engine* e, int32_t log2_buckets, int32_t max_stones
     int rc = AF_OK;
     if (rc == AF_OK) rc = dalloc(e, &P.memo_key, NE * MK);
     if (rc == AF_OK) rc = dalloc(e, &P.memo_pv, NE * CP);
+    if (rc == AF_OK) rc = dalloc(e, &P.memo_val, NE);
     if (rc == AF_OK) rc = dalloc(e, &P.memo_lock, NE);
     if (rc == AF_OK) rc = dalloc(e, &P.memo_stats, (size_t)MEMO_N);
     if (rc != AF_OK) return rc;
     P.memo_bucket_mask = (uint32_t)((1ull << log2_buckets) - 1ull);
     P.memo_max_stones = max_stones;
+    P.memo_epoch = 1;
     P.memo_budget = P.budget < 6 ? P.budget : 6;      // profiles/r5_31: 5 and 8 give the same moves/s (fewer yields vs a shorter launch)
-    if (const char* b = getenv("AF_MEMO_BUDGET")) { const int v = atoi(b); if (v > 0) P.memo_budget = v; }
+    if (const char* b = getenv("AF_MEMO_BUDGET")) { const int v = atoi(b); if (v > 0) { P.memo_budget = v; e->memo_budget_fixed = true; } }
     e->memo_entries = NE;
     e->memo = true;
     return AF_OK;
@@ -1642,10 +1655,20 @@ int af_engine_memo_insert(af_engine* e, void* stream, const float* policy_dev, c
 int af_engine_memo_clear(af_engine* e, void* stream) {
     if (!e || !e->memo) return AF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // keys only: an all-zero key row is an empty entry; lock words and the serial keep counting
-    HIP_OK(hipMemsetAsync(e->P.memo_key, 0, e->memo_entries * 4 * (size_t)e->KW * 8, st));
+    // O(1): launches enqueued from now on carry the next epoch, under which no stored entry matches and every way counts as empty
+    // (EngineParams travel by value, so this is stream-ordered like the memset it replaces; a captured graph has the epoch baked
+    // in — af_engine_memo_epoch is part of what its owner keys it on).  Lock words and the serial keep counting.  Only when the
+    // 32-bit epoch would wrap are the keys really zeroed.
+    if (e->P.memo_epoch == 0xffffffffu) {
+        HIP_OK(hipMemsetAsync(e->P.memo_key, 0, e->memo_entries * 4 * (size_t)e->KW * 8, st));
+        e->P.memo_epoch = 1;
+    } else {
+        ++e->P.memo_epoch;
+    }
     return AF_OK;
 }
+
+int64_t af_engine_memo_epoch(af_engine* e) { return (e && e->memo) ? (int64_t)e->P.memo_epoch : 0; }
 
 int af_engine_memo_stats(af_engine* e, void* stream, uint64_t* out) {
     if (!e || !e->memo || !out) return AF_ERR_ARG;
@@ -1891,6 +1914,7 @@ int af_engine_set_tick_budget(af_engine* e, int32_t selects_per_launch) {
     if (!e || selects_per_launch < 1) return AF_ERR_ARG;
     e->P.budget = selects_per_launch;
     if (e->P.budget_hard < selects_per_launch) e->P.budget_hard = selects_per_launch;
+    if (e->memo && !e->memo_budget_fixed) e->P.memo_budget = selects_per_launch < 6 ? selects_per_launch : 6;   // stays min(budget, 6)
     return AF_OK;
 }
 

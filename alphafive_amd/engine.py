@@ -88,6 +88,8 @@ def lib():
         L.af_engine_memo_insert.argtypes = [vp, vp, vp, vp]
         L.af_engine_memo_clear.argtypes = [vp, vp]
         L.af_engine_memo_stats.argtypes = [vp, vp, u64p]
+        L.af_engine_memo_epoch.argtypes = [vp]
+        L.af_engine_memo_epoch.restype = C.c_int64
         L.af_engine_tree_dump.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
         L.af_engine_load_tree.argtypes = [vp, C.c_int32, C.c_int32, u64p, i32p, i32p, f32p, f32p, u8p]
         L.af_state_to_key.argtypes = [C.c_char_p, C.c_int32, u64p]
@@ -171,7 +173,7 @@ class Engine:
     def params_key(self):
         """Everything set_training / set_simulations / set_tick_budget can change: part of the key of any captured graph."""
         p = self._params
-        return (p["training"], p["sims"], p["upper"], p["tick_budget"], p.get("memo"))
+        return (p["training"], p["sims"], p["upper"], p["tick_budget"], p.get("memo_epoch"), p.get("memo"))
 
     def set_training(self, training):
         _check(lib().af_engine_set_training(self._h, int(training)), "af_engine_set_training")
@@ -230,11 +232,15 @@ class Engine:
                     max_wave_us=float(out[96]) * 0.01)
 
     # ---- evaluation memo (include/af_engine.h, ABI v5): off unless memo_enable() was called ----
-    def memo_enable(self, log2_buckets=20, max_stones=5):
+    def memo_enable(self, log2_buckets=18, max_stones=5):
         """Share evaluations between the games of this engine: positions with <= max_stones stones, 4 << log2_buckets entries
-        (584 B each at 11x11, 1160 B at 15x15).  Trees stay bit-identical; a launch's parameters change (params_key)."""
+        (588 B each at 11x11, 1164 B at 15x15: the default table is 0.6 / 1.2 GB — memo_bytes says what was allocated; bench.py's
+        22:5 is 9.9 GB).  Trees stay bit-identical; a launch's parameters change (params_key)."""
         _check(lib().af_engine_memo_enable(self._h, int(log2_buckets), int(max_stones)), "af_engine_memo_enable")
+        kw = self.KW2 // 2
+        self.memo_bytes = (4 << int(log2_buckets)) * (32 * kw + 256 * kw + 12)
         self._params["memo"] = (int(log2_buckets), int(max_stones))
+        self._params["memo_epoch"] = int(lib().af_engine_memo_epoch(self._h))
 
     @property
     def memo(self):
@@ -245,8 +251,10 @@ class Engine:
         _check(lib().af_engine_memo_insert(self._h, stream, policy_ptr, value_ptr), "af_engine_memo_insert")
 
     def memo_clear(self, stream=None):
-        """The evaluator's weights changed: forget everything (stream-ordered)."""
+        """The evaluator's weights changed: forget everything (stream-ordered, O(1): the launches that follow carry a new epoch
+        under which no stored entry matches — the epoch is part of params_key(), so a captured graph is dropped with it)."""
         _check(lib().af_engine_memo_clear(self._h, stream), "af_engine_memo_clear")
+        self._params["memo_epoch"] = int(lib().af_engine_memo_epoch(self._h))
 
     def memo_stats(self, stream=None):
         out = np.zeros(6, np.uint64)
@@ -434,7 +442,8 @@ class SelfPlayEngine:
         has no weights the engine could know about (a stub).  Sources, in order: the caller's weights_version=, the
         evaluator's own .weights_version (net_hip.make_eval's closure, tower_hip), the `version` of the object a bound method
         belongs to (pv_device=net.eval_device).  An evaluator that takes bind_outputs (i.e. one of ours, whose Python wrapper
-        is the only place that reloads weights) without any version source would replay stale weights silently: refuse."""
+        is the only place that reloads weights) without any version source would replay stale weights silently: refused — by
+        run_ticks_graph() and by eval_memo=, not by the constructor (eager tick() users are not affected)."""
         if explicit is not None:
             return explicit if callable(explicit) else (lambda: explicit)
         pv = self.pv_device
@@ -445,8 +454,9 @@ class SelfPlayEngine:
         if owner is not None and hasattr(owner, "version"):
             return lambda: owner.version
         if hasattr(pv, "bind_outputs"):
-            raise EngineError("run_ticks_graph: pv_device takes bind_outputs but exposes no weights_version; pass "
-                              "SelfPlayEngine(..., weights_version=lambda: net.version)")
+            # one of ours without a version source: eager tick() is fine (the Python wrapper reloads), anything that replays
+            # launches or reuses stored bits (run_ticks_graph, eval_memo) is refused where it is asked for
+            self._weights_version_missing = True
         return None
 
     def _graph_key(self, n):
@@ -462,6 +472,9 @@ class SelfPlayEngine:
         captured again (same protocol as Player._search_batch).  A failing capture raises: there is no silent eager fallback.
         timed=True brackets the replay with HIP timing events on its stream and appends them to self.replay_events."""
         torch = self.torch
+        if getattr(self, "_weights_version_missing", False):
+            raise EngineError("run_ticks_graph: pv_device takes bind_outputs but exposes no weights_version (a replayed graph "
+                              "would keep evaluating with stale weights); pass SelfPlayEngine(..., weights_version=lambda: net.version)")
         key = self._graph_key(n)
         if self._graph is None or self._graph[0] != key:
             self._graph = None

@@ -51,6 +51,7 @@ class HipNet(object):
     def __init__(self, variables, board_size, max_batch, device):
         self.S, self.max_batch, self.device = board_size, max_batch, torch.device(device)
         self._h = C.c_void_p()
+        self._version = 0
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _check(lib().af_net_create(board_size, max_batch, idx, C.byref(self._h)), "af_net_create")
         self.load(variables)
@@ -66,6 +67,11 @@ class HipNet(object):
             _check(lib().af_net_set_variable(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size),
                    f"af_net_set_variable({name})")
         _check(lib().af_net_finalize(self._h), "af_net_finalize")
+        self._version += 1
+
+    def weights_version(self):
+        """Count of load() calls: what a captured graph over this handle (SelfPlayEngine.run_ticks_graph) is keyed on."""
+        return self._version
 
     def bind_outputs(self, policy, value):
         """Write results straight into caller-owned device tensors (no copy on the tick path)."""
@@ -145,8 +151,11 @@ _SPLIT_MAC_PER_PIXEL = sum(9 * ci * co + 9 * co * co + ci * co for ci, co in ((3
 _SPLIT_BYTES_PER_POSITION = (28 * 16384 + 17 * 15488 + 2 * (4 + 16) * 121 * 2 * 2 + 3 * 121 * 4 + 122 * 4)
 
 
+_conv_mode = 5          # af_net_tune(0, .) as last set through tune(): 5 = the split-operand path (the library's default on 11x11 / 15x15)
+
+
 def roofline_info(board_size=11):
-    if board_size == 15:
+    if board_size == 15 and _conv_mode == 5:
         # the same kernels on two half-board pseudo-positions per board (8 pixel tiles of 32 for 225 pixels): MFMA work per
         # position = 256 / 121 of the 11x11 figure; HBM slabs are 32 KB (reads: 2 x 20 KB windows, writes 2 x 15.5 / 12.4 KB)
         return {"backend": "hip (af_conv_f16s.hip on 15x15: two half-board pseudo-positions per board, fp16 split operands, fp32 "
@@ -156,7 +165,7 @@ def roofline_info(board_size=11):
                           "forward timed)",
                 "peak_tflops": 2500.0, "issued_flop_per_position": 2 * 3 * _SPLIT_MAC_PER_PIXEL * 256,
                 "algorithmic_bytes_per_position": (30 * 2 * 20480 + 19 * 30720 + 2 * 2 * 2 * 16384 + 2 * (4 + 16) * 225 * 2 * 2 + 3 * 225 * 4 + 226 * 4)}
-    if board_size == 11:
+    if board_size == 11 and _conv_mode == 5:
         return {"backend": "hip (af_conv_f16s.hip: stem, convs and heads on v_mfma_f32_32x32x16_f16 with fp16 split operands and "
                            "fp32 accumulation; convs weight-stationary with an LDS-DMA slab ring)",
                 "kernel": "af_net_forward = af_stem_mfma_f16s + 6x af_conv_f16s + 2x af_block_f16s (blocks 3 and 5: both convolutions "
@@ -164,6 +173,9 @@ def roofline_info(board_size=11):
                           "(whole forward timed; the convolution kernels carry 99 % of the algorithmic FLOPs, each MAC issued as 3 fp16 MFMA MACs)",
                 "peak_tflops": 2500.0, "issued_flop_per_position": 2 * 3 * _SPLIT_MAC_PER_PIXEL * 121,
                 "algorithmic_bytes_per_position": _SPLIT_BYTES_PER_POSITION}
+    if _conv_mode == 0:
+        return {"backend": "hip (af_net.hip: fp32 MFMA direct implicit-GEMM convs, fused bias/ELU/residual)", "peak_tflops": 157.3,
+                "kernel": "af_net_forward = af_stem_conv + 10x af_conv_mfma + head kernels (whole forward timed; fp32 operands, v_mfma_f32_32x32x2_f32)"}
     return {"backend": "hip (af_net.hip: fp32 MFMA Winograd F(2x2,3x3) convs, fused transforms/bias/ELU/residual)",
             "kernel": "af_net_forward = af_stem_conv + 10x af_conv_wino + af_value_head + af_policy_head "
                       "(whole forward timed; af_conv_wino carries 97 % of the algorithmic FLOPs; achieved = "
@@ -175,5 +187,8 @@ def tune(key, value):
     """Benchmark knob (af_net_tune, include/af_net.h): key 0 = conv path (5 fp16 split-operand implicit GEMM = default
     on 11x11, 1 fp32 Winograd, 2 Winograd + LDS-shared U, 3 / 4 Winograd variants, 0 fp32 direct); key 1/2 = sub-batch
     streams/size; key 3 / 7 = ablation variants (profiling only)."""
+    global _conv_mode
     lib().af_net_tune.argtypes = [C.c_int32, C.c_int32]
     _check(lib().af_net_tune(key, value), "af_net_tune")
+    if key == 0:
+        _conv_mode = int(value)

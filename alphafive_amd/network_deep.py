@@ -27,8 +27,9 @@ class _HipEvaluator(object):
 
     def weights_version(self):
         """What a captured graph of this evaluator is keyed on (SelfPlayEngine.run_ticks_graph): the tower packs its weights
-        once, at select_backend(); a new weight set means a new evaluator object."""
-        return id(self.net._tower)
+        once, at select_backend(); every (re)build of the tower bumps the net's pack counter (a monotone count, not id(): CPython
+        may hand a freed tower's id to its successor)."""
+        return self.net._pack_version
 
 
 class DeepResNet(object):
@@ -58,18 +59,22 @@ class DeepResNet(object):
         return 2 * mac
 
     @torch.no_grad()
-    def eval_device(self, x):
+    def eval_device(self, x, dtype=None):
+        """All-PyTorch evaluation in self.dtype (bf16), or — dtype=torch.float32 — of the SAME (bf16-valued) weights in fp32
+        arithmetic with fp32 activations: the yardstick both bf16 paths' errors are measured against (tests/test_gpu_realnet.py)."""
+        dt = self.dtype if dtype is None else dtype
+        c = (lambda wb: (wb[0].to(dt), wb[1].to(dt)))
         B = x.shape[0]
-        h = F.elu(F.conv2d(x.to(self.dtype), self.stem[0], self.stem[1], padding=2))
+        h = F.elu(F.conv2d(x.to(dt), *c(self.stem), padding=2))
         for blk in self.tower:
-            r = F.conv2d(h, *blk["res"])
-            g = F.elu(F.conv2d(h, *blk["c1"], padding=1))
-            h = F.elu(r + F.conv2d(g, *blk["c2"], padding=1))
-        v = F.elu(F.conv2d(h, *self.vconv)).reshape(B, -1)
-        v = F.elu(v @ self.vfc1[0] + self.vfc1[1])
-        v = torch.tanh((v @ self.vfc2[0] + self.vfc2[1]).float() / 2).squeeze(1)
-        p = F.elu(F.conv2d(h, *self.pconv)).reshape(B, -1)
-        p = torch.softmax((p @ self.pfc[0] + self.pfc[1]).float(), dim=1)
+            r = F.conv2d(h, *c(blk["res"]))
+            g = F.elu(F.conv2d(h, *c(blk["c1"]), padding=1))
+            h = F.elu(r + F.conv2d(g, *c(blk["c2"]), padding=1))
+        v = F.elu(F.conv2d(h, *c(self.vconv))).reshape(B, -1)
+        v = F.elu(v @ self.vfc1[0].to(dt) + self.vfc1[1].to(dt))
+        v = torch.tanh((v @ self.vfc2[0].to(dt) + self.vfc2[1].to(dt)).float() / 2).squeeze(1)
+        p = F.elu(F.conv2d(h, *c(self.pconv))).reshape(B, -1)
+        p = torch.softmax((p @ self.pfc[0].to(dt) + self.pfc[1].to(dt)).float(), dim=1)
         return p, v
 
     # ---- hand-written tower (csrc/af_tower_bf16.hip) ----
@@ -81,6 +86,7 @@ class DeepResNet(object):
         if name != "hip":
             raise ValueError(name)
         from . import tower_hip
+        self._pack_version = getattr(self, "_pack_version", 0) + 1
         self._tower = tower_hip.HipTower(self.tower, self.board_size, self.width, max_batch, self.device,
                                          stem=self.stem, vconv=self.vconv, pconv=self.pconv,
                                          dense=(self.vfc1[0], self.vfc1[1], self.vfc2[0], self.vfc2[1], self.pfc[0], self.pfc[1]))

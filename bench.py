@@ -322,6 +322,8 @@ def live_pmc(G, ticks=400, last=200, timeout_s=180, probe="probe_tick_min.py", e
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+FP32_LEG_MODE = 1      # fastest fp32-MFMA path at 4096 positions: Winograd register ring, 3.48 ms vs 1.42 (tools/probe_arith_width.py, profiles/r6_02)
+
 EXTRA_LEGS = {
     # BASELINE.json configs[3]: 15x15, 800 sims/move (cap 942 = the reference's 642 - 500 head-room), 4096 games
     "config4": ["--board", "15", "--sims", "800", "--upper", "942", "--games", "4096", "--age-plies", "24", "--warmup", "3", "--steps", "6"],
@@ -329,6 +331,9 @@ EXTRA_LEGS = {
     "config5": ["--net", "deep-bf16", "--games", "8192", "--age-plies", "12", "--warmup", "3", "--steps", "8"],
     # the headline workload once more with the evaluation memo on (same trees, fewer forwards): reported beside the headline, never as it
     "config2_memo": ["--eval-memo", "22:5", "--warmup", "5", "--steps", "20"],
+    # the headline workload on arithmetic of the reference's own width: the fp32-MFMA convolution path (24 mantissa bits, 157.3
+    # TFLOP/s matrix peak) instead of the 22-bit fp16 split-operand scheme — what the split buys, on the same line
+    "config2_fp32mfma": ["--conv-mode", str(FP32_LEG_MODE), "--age-plies", "12", "--warmup", "2", "--steps", "4"],
 }
 
 
@@ -371,6 +376,9 @@ def extra_config_legs(timeout_s=240, wall_budget_s=600.0):
                      name + "_steps": j["steps"], name + "_ms_per_step": j["ms_per_step"], name + "_wall_s": time.time() - t0})
         if "mfma_issued_frac" in rf:
             flat[name + "_mfma_issued_frac"] = rf["mfma_issued_frac"]
+        for k in ("dv_max_vs_torch_fp32", "dp_max_vs_torch_fp32", "operand_mantissa_bits"):
+            if k in rf:
+                flat[name + "_" + k] = rf[k]
         if j["config"].get("eval_memo"):
             flat[name + "_hits_per_simulation"] = j["config"]["eval_memo"]["hits_per_simulation"]
         full[name] = {"cmd": " ".join(["python", "bench.py"] + cmd[2:]), "metric": j["metric"], "value": j["value"], "dtype": j["dtype"],
@@ -482,6 +490,10 @@ def main():
                          "the default run measures it in a leg of its own (config2_memo_*)")
     ap.add_argument("--pipe-values", action="store_true",
                     help="W / Q in fp64: the arithmetic of main.py's pipe-fed workers (networkAPI.py:72); default = the pv_fn path")
+    ap.add_argument("--conv-mode", type=int, default=5, choices=[0, 1, 2, 3, 4, 5],
+                    help="af_net_tune(0, .): 5 (default) = fp16 split-operand implicit GEMM (22 mantissa bits, 3 fp16 MFMA products per "
+                         "MAC); 0..4 = the fp32-MFMA paths of af_net.hip (24 bits, the reference's width): 0 direct, 1-4 Winograd F(2x2,3x3) "
+                         "variants.  The default run measures mode %d in a leg of its own (config2_fp32mfma_*)" % FP32_LEG_MODE)
     ap.add_argument("--net", default="hip", choices=["hip", "torch", "deep-bf16", "deep-bf16-torch"],
                     help="hip (default): the hand-written kernels, fails without libaf_net.so; torch: PyTorch-ROCm ops "
                          "(reference only); deep-bf16 = BASELINE configs[4]: 8-block width-128 net in bf16 (use with --games 8192)")
@@ -539,6 +551,11 @@ def main():
         pv = deep.select_backend("torch" if args.net.endswith("torch") else "hip", G)   # "hip" raises without libaf_tower.so
     else:
         pv = net.select_backend(args.net)
+        if args.conv_mode != 5:
+            if args.net != "hip" or cfg.board_size not in (11, 15):
+                raise SystemExit("--conv-mode selects a path of the hand-written 11x11 / 15x15 forward (--net hip)")
+            from alphafive_amd import net_hip
+            net_hip.tune(0, args.conv_mode)
     memo = None
     if args.eval_memo:
         lb, ms = (int(x) for x in args.eval_memo.split(":"))
@@ -548,7 +565,7 @@ def main():
 
     ev_tick, ev_net = [], []
     timing = {"on": False}
-    gathered = {"episodes": 0, "plies": 0}
+    gathered = {"episodes": 0, "plies": 0, "by_rank": [0] * world, "max_gid": -1}
 
     def one_tick():
         if timing["on"]:
@@ -628,6 +645,10 @@ def main():
         else:
             got = gat.flush(unpack=False) if last else gat.collect(unpack=False)
             n_eps, n_plies = sum(p.n for p in got), sum(p.plies for p in got)
+            for p in got:                             # (rank 0 only; headers only: who sent what, and the largest global game id)
+                gathered["by_rank"][p.rank] += p.n
+                if p.n:
+                    gathered["max_gid"] = max(gathered["max_gid"], p.rank * G + int(p.buf[4:4 + 4 * p.n:4].max()))
         if rank == 0:
             gathered["episodes"] += n_eps
             gathered["plies"] += n_plies
@@ -714,7 +735,8 @@ def main():
     me = {"rank": rank, "device": "cuda:%d" % local, "name": props.name,
           "uuid": str(getattr(props, "uuid", "")),
           "pci_bus_id": "%s:%s:%s" % (getattr(props, "pci_domain_id", "?"), getattr(props, "pci_bus_id", "?"), getattr(props, "pci_device_id", "?")),
-          "episodes_finished": int(ct1["episodes"] - ct0["episodes"]), "plies": int(plies), "elapsed_s": elapsed}
+          "episodes_finished": int(ct1["episodes"] - ct0["episodes"]), "episodes_total": int(ct1["episodes"]), "plies": int(plies),
+          "elapsed_s": elapsed}
     ranks_info = [me]
     if world > 1:
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
@@ -740,6 +762,16 @@ def main():
     gathered_total, finished_total = int(got_total.item()), int(fin_total.item())
 
     if rank == 0:
+        arith = None
+        if deep is None and args.net == "hip":
+            # arithmetic width on the line: the live leaf batch of the last tick through the kernels once more
+            # (same bits: the forward is deterministic) and through ResNet.eval_torch = PyTorch-ROCm fp32 ops, product side, no oracle
+            pl, vl = (x_.clone() for x_ in pv(sp.planes))
+            pt_, vt_ = net.eval_torch(sp.planes)
+            arith = {"dv_max_vs_torch_fp32": float((vl - vt_).abs().max().item()), "dp_max_vs_torch_fp32": float((pl - pt_).abs().max().item()),
+                     "dv_mean_vs_torch_fp32": float((vl - vt_).abs().mean().item()), "positions": int(G),
+                     "operand_mantissa_bits": 22 if args.conv_mode == 5 and cfg.board_size in (11, 15) else 24}
+            del pl, vl, pt_, vt_
         d = {k: ct1[k] - ct0[k] for k in ct1}
         n_ticks = ticks_timed                       # every tick of the timed region (graph replays + the event-timed sample)
         tick_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_tick]))
@@ -759,6 +791,8 @@ def main():
         peak, dtype_name = roof.get("peak_tflops", PEAK_FP32_MFMA_TFLOPS), "f32"
         if roof["backend"].startswith("hip") and "f16" in roof["backend"]:
             dtype_name = "f32 (fp16x2 split operands: 3 fp16 MFMA products per MAC, fp32 accumulate)"
+        elif roof["backend"].startswith("hip"):
+            dtype_name = "f32 (fp32 MFMA operands, fp32 accumulate)"
         if deep is not None:
             flop_pos, peak, dtype_name = deep.flops_per_position(), 2500.0, "bf16"   # dense bf16 MFMA peak
         net_tflops = G * flop_pos / (net_ms * 1e-3) / 1e12
@@ -771,7 +805,7 @@ def main():
         tp = next((q for q in (os.path.join(REPO, "profiles", "r%d_pmc_hbm_traffic.json" % r) for r in (5, 4, 3)) if os.path.exists(q)),
                   os.path.join(REPO, "profiles", "r3_pmc_hbm_traffic.json"))
         tp_name = "profiles/" + os.path.basename(tp)
-        if os.path.exists(tp) and deep is None and roof["backend"].startswith("hip"):
+        if os.path.exists(tp) and deep is None and roof["backend"].startswith("hip") and args.conv_mode == 5:
             with open(tp) as f:
                 prof = json.load(f)
             if prof["workload"] == {"games": G, "board_size": cfg.board_size}:
@@ -804,8 +838,9 @@ def main():
                                     f"training-mode MCTS, 8-block x 128 residual net in bf16 (random init), batched leaf eval")
                        if deep is not None else
                        (f"BASELINE configs[1]: {G} concurrent 11x11 games per GPU, {args.sims} sims/move "
-                        f"(cap {args.upper}), training-mode MCTS, alphaFive-6960 net (fp32-class: fp16 split operands, "
-                        f"fp32 accumulate; within 1e-5 of the fp64 restatement), batched leaf eval")
+                        f"(cap {args.upper}), training-mode MCTS, alphaFive-6960 net ("
+                        + ("fp32-class: fp16 split operands, fp32 accumulate" if args.conv_mode == 5 else "fp32 MFMA operands, af_net_tune(0, %d)" % args.conv_mode)
+                        + "; within 1e-5 of the fp64 restatement), batched leaf eval")
                        if cfg.board_size == 11 else
                        (f"BASELINE configs[3]-style: {G} concurrent {cfg.board_size}x{cfg.board_size} games per GPU, "
                         f"{args.sims} sims/move (cap {args.upper}), random-init net of the same architecture, fp32"),
@@ -832,6 +867,12 @@ def main():
                                      "elapsed_s": r["elapsed_s"]} for r in ranks_info],
                        "episodes_gathered_total": gathered_total, "episodes_finished_total_all_ranks": finished_total,
                        "gathered_equals_finished": gathered_total == finished_total,
+                       # N > 1: whose episodes rank 0 holds, read off the packed headers it received (source rank r's games are
+                       # the global ids r*G .. r*G + G-1), against every rank's own device counter
+                       "episodes_gathered_by_source_rank": gathered["by_rank"] if world > 1 else None,
+                       "episodes_finished_by_rank_total": [r["episodes_total"] for r in ranks_info] if world > 1 else None,
+                       "max_global_game_id_gathered": gathered["max_gid"] if world > 1 else None,
+                       "gather_ring_allocations": gat.allocations if gat is not None else None,
                        # rank 0's host time in the per-step hand-off (collect + pack launch + post), wall clock, inside the timed
                        # region: what the other ranks would wait for at max-over-ranks timing
                        "rank0_handoff_ms_per_step": 1e3 * handoff["s"] / max(1, handoff["n"])},
@@ -871,6 +912,11 @@ def main():
             out["roofline"]["hbm_algorithmic_bytes_per_launch"] = hb
             out["roofline"]["hbm_algorithmic_gbs"] = hb / (net_ms * 1e-3) / 1e9
             out["roofline"]["hbm_frac_of_peak"] = hb / (net_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+        if arith is not None:
+            out["roofline"].update(arith)
+            out["roofline"]["arithmetic_note"] = ("d*_vs_torch_fp32: this run's live leaf batch, kernels vs ResNet.eval_torch (PyTorch-ROCm fp32 ops); the "
+                                                  "tests hold the value to 1e-5 of the fp64 restatement; config2_fp32mfma_* = the same workload on the "
+                                                  "fp32-MFMA path (24-bit operands)")
         out["roofline"]["power"] = power_report                 # the board's sensor over the timed region (None without one)
         if pmc is not None and "sustained_clock_ghz" in pmc:
             # what DESIGN argues from the counters, reproducible from this line alone: the chip is power-bound under this load, so the

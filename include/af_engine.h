@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 5
+#define AF_ABI_VERSION 6
 
 /* engine modes */
 #define AF_MODE_SELFPLAY 0   /* Player.run loop on device: games restart forever (main.py:82 gen_data) */
@@ -162,17 +162,21 @@ int af_engine_counters(af_engine* e, void* stream, uint64_t* out);
  * reaches an unseen position holding at most `max_stones` stones looks it up (4-way buckets, exact key = both bitboards + last
  * move) and on a hit expands it at once (player.py:186-202) and goes on with its next simulation inside the same launch.  Every
  * game still owns its tree and every tree is bit-identical to the run without the memo; only the number of ticks differs.
- *   af_engine_memo_enable  allocates 4 << log2_buckets entries of (32 KW + 256 KW + 8) bytes; once per engine.
+ *   af_engine_memo_enable  allocates 4 << log2_buckets entries of (32 KW + 256 KW + 12) bytes; once per engine.
  *   af_engine_memo_insert  enqueue after the forward of a tick (same stream): stores the evaluations of the leaves parked by the
  *                          last af_engine_tick, read from the same policy/value buffers the next tick will consume.
  *   af_engine_memo_clear   enqueue whenever the evaluator's weights change (stream-ordered): the stored bits are the old net's.
- *                          (A memset of the key rows: meant for weights that are synchronised in intervals, not at every step.)
+ *                          O(1) since ABI v6: every entry carries the epoch it was written in, a clear bumps the epoch the
+ *                          following launches are issued with, older entries stop matching and their ways count as empty.
+ *   af_engine_memo_epoch   (ABI v6) the current epoch (>= 1; 0 = memo off).  Launch parameters travel by value: whoever replays a
+ *                          captured graph of af_engine_tick / af_engine_memo_insert keys it on this as well.
  *   af_engine_memo_stats   out[0..5] = launches, probes, hits, inserts, replacements, entries allocated (synchronises). */
 #define AF_MEMO_STATS 6
 int af_engine_memo_enable(af_engine* e, int32_t log2_buckets, int32_t max_stones);
 int af_engine_memo_insert(af_engine* e, void* stream, const float* policy_dev, const float* value_dev);
 int af_engine_memo_clear(af_engine* e, void* stream);
 int af_engine_memo_stats(af_engine* e, void* stream, uint64_t* out);
+int64_t af_engine_memo_epoch(af_engine* e);
 
 /* launch-shape evidence, accumulated over all games and launches since the last reset:
  * out[0..63] = histogram of selects per game and launch (63 = 63 or more), out[64..95] = histogram of

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in af_engine.h but not exported"
     lib.af_abi_version.restype = ctypes.c_int
-    assert lib.af_abi_version() == 5
+    assert lib.af_abi_version() == 6
 
 
 def test_state_key_codec_roundtrip(lib):

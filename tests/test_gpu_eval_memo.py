@@ -173,3 +173,118 @@ def test_bench_reports_the_memo_leg_keys():
     assert m["log2_buckets"] == 12 and m["max_stones"] == 5 and m["entries"] == 4 << 12
     assert m["probes"] >= m["hits"] > 0 and m["inserts"] > 0 and 0 < m["hits_per_simulation"] < 1
     assert d["unit"] == "moves/s" and d["config"]["games_per_gpu"] == 512 and "power" in d["roofline"]
+
+
+def test_memo_on_a_16x16_board_keeps_the_value_out_of_the_policy_row():
+    """on 16x16 a policy row has no spare slot (C == 256 == the row's stride), the value used to be looked for
+    at row[C] = the next entry's first prior.  The value lives in an array of its own now: memo run == plain run == oracle."""
+    from alphafive_amd.engine import SelfPlayEngine
+    cfg = make_cfg(board_size=16, goal=5, simulation_per_step=40, upper_simulation_per_step=50)
+    salt, peak, seed, G = 5, 16384, 8, 32
+    pv = lambda x: pseudonet.pseudonet_torch(x, salt, peak)                  # noqa: E731
+    a = SelfPlayEngine(cfg, G, pv, device=0, seed=seed, weights_version=0, eval_memo=dict(log2_buckets=6, max_stones=6))
+    b = SelfPlayEngine(cfg, G, pv, device=0, seed=seed)
+    got_a = _run_until(a, 12 * G)
+    got_b = _run_until(b, 12 * G)
+    st = a.engine.memo_stats()
+    assert st["hits"] > 200 and st["replaced"] > 0
+    for g in (0, G - 1):                                                     # whole trees, mid-game
+        ta, tb = a.engine.tree_dump(g), b.engine.tree_dump(g)
+        na, nb = {k.tobytes(): i for i, k in enumerate(ta["keys"])}, {k.tobytes(): i for i, k in enumerate(tb["keys"])}
+        common = [k for k in na if k in nb]
+        assert len(common) > 50
+        for k in common:
+            i, j = na[k], nb[k]
+            assert (ta["p"][i].view(np.uint32) == tb["p"][j].view(np.uint32)).all()
+    orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=seed, game_id=3, pseudo_salt=salt, pseudo_peak=peak)
+    state, last = oracle.board_to_state(np.zeros((16, 16), np.int8)), None
+    # the committed plies of game 3 so far are in its record buffer only once the episode ends; compare through move results of a
+    # fresh pair of engines instead: first 3 moves of game 3, visit counts bit for bit
+    a.close(), b.close()
+    from alphafive_amd.engine import Engine, MODE_EXTERNAL, state_to_key
+    import torch
+    ext = Engine(cfg, 4, device=0, mode=MODE_EXTERNAL, training=True, seed=seed, first_game_id=0)   # game 3 = the oracle's; 0..2 fill the memo
+    ext.memo_enable(6, 6)
+    pol = torch.zeros((4, 256), device="cuda")
+    val = torch.zeros((4,), device="cuda")
+    planes = torch.zeros((4, 3, 16, 16), device="cuda")
+    st_ = torch.cuda.current_stream().cuda_stream
+    for ply in range(3):
+        key, lc = state_to_key(state, 16), -1 if last is None else last[0] * 16 + last[1]
+        ext.set_roots([0, 1, 2, 3], np.stack([key] * 4), [lc] * 4)
+        for _ in range(200):
+            ext.tick(pol.data_ptr(), val.data_ptr(), planes.data_ptr(), st_)
+            p, v = pv(planes)
+            pol.copy_(p), val.copy_(v)
+            ext.memo_insert(pol.data_ptr(), val.data_ptr(), st_)
+            if (ext.status(st_) == 2).all():
+                break
+        act, _, vis, _ = ext.move_result(3)
+        opol, oact, ovis = orc.get_action(state, last)
+        assert (vis == ovis).all() and (act // 16, act % 16) == oact, ply
+        board = oracle.step(oracle.state_to_board(state, 16), oact)
+        state, last = oracle.board_to_state(board), oact
+    assert ext.memo_stats()["hits"] > 0                                       # transpositions of the first moves came from the memo
+    ext.close()
+
+
+def test_memo_clear_is_an_epoch_bump_and_the_tick_budget_keeps_the_memo_budget_below_it():
+    """ADVICE r5 (low x2): af_engine_memo_clear is O(1) (entries carry the epoch they were written in; the epoch is part of
+    params_key so a captured graph goes with it), and af_engine_set_tick_budget re-derives the memo's own yield budget."""
+    from alphafive_amd.engine import SelfPlayEngine
+    cfg = make_cfg(board_size=6, goal=4, simulation_per_step=30, upper_simulation_per_step=40)
+    salt, peak, seed, G = 3, 16384, 2, 32
+    ver = [0]
+    a = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, salt, peak), device=0, seed=seed,
+                       weights_version=lambda: ver[0], eval_memo=dict(log2_buckets=6, max_stones=6))
+    b = SelfPlayEngine(cfg, G, lambda x: pseudonet.pseudonet_torch(x, salt, peak), device=0, seed=seed)
+    k0 = a.engine.params_key()
+    got_a = _run_until(a, 20 * G, graph=True)
+    h0 = a.engine.memo_stats()
+    assert h0["hits"] > 100
+    ver[0] = 1                                            # "new weights" (the same function here: the trees must not change)
+    got_a += _run_until(a, 40 * G, graph=True)
+    k1 = a.engine.params_key()
+    assert k1 != k0 and a.engine._params["memo_epoch"] == 2
+    h1 = a.engine.memo_stats()
+    assert h1["inserts"] > h0["inserts"] and h1["hits"] > h0["hits"]          # refilled under the new epoch, and hit again
+    a.engine.set_tick_budget(3)                           # below 6: the memo's yield budget follows it down
+    got_a += _run_until(a, 60 * G, graph=True)
+    got_b = _run_until(b, 60 * G)
+    ca, cb = _common(got_a, got_b)
+    assert len(ca) >= G
+    _same_episodes(ca, cb)
+    a.close(), b.close()
+
+
+def test_eager_ticks_do_not_need_a_weight_version_but_graph_replay_does():
+    """an evaluator with bind_outputs and no version source is fine for eager tick(); run_ticks_graph refuses it."""
+    from alphafive_amd.engine import SelfPlayEngine, EngineError
+    cfg = make_cfg(board_size=6, goal=4, simulation_per_step=20, upper_simulation_per_step=30)
+
+    class Stub:
+        def __call__(self, x):
+            return pseudonet.pseudonet_torch(x, 1, 0)
+
+        def bind_outputs(self, p, v):
+            pass
+    sp = SelfPlayEngine(cfg, 8, Stub(), device=0, seed=1)
+    sp.run_ticks(30)
+    sp.check()
+    assert sp.counters()["plies"] >= 8
+    with pytest.raises(EngineError, match="weights_version"):
+        sp.run_ticks_graph(4)
+    sp.close()
+    from alphafive_amd.network import ResNet
+    from alphafive_amd.net_hip import HipNet
+    net = ResNet(6, device="cuda", seed=2)
+    h = HipNet(net.variables, 6, 8, net.device)           # a raw handle: counts its own load() calls
+    v0 = h.weights_version()
+    sp = SelfPlayEngine(cfg, 8, h, device=0, seed=1)
+    sp.run_ticks_graph(4)
+    k0 = sp._graph[0]
+    h.load(net.variables)
+    assert h.weights_version() == v0 + 1
+    sp.run_ticks_graph(4)
+    assert sp._graph[0] != k0
+    sp.close()

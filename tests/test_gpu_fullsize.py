@@ -3,6 +3,8 @@
 finished at least one episode; complete episodes of sampled games bit-exact vs the oracle, size-independent
 invariants on all games, and shard invariance (games g..g+n of a big engine == the same games run in their own
 engine with first_game_id = g — the single-GPU form of the 8-GPU sharding check)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -141,7 +143,52 @@ def test_config4_full_size_15x15_invariants_oracle_and_sharding():
             assert (d["n"][i] >= od["n"][j]).all()
             hits += 1
         assert hits > 300
+    # ... and EXACTLY at the one-move point (the comparison above can only say ">=" because the second move's
+    # simulations are under way in SELFPLAY mode): the same 4096 games as an EXTERNAL-mode engine, which holds a game at MOVE_DONE,
+    # so every tree is frozen the moment its move is committed — sampled games' whole trees (N, W bits, P bits, sum_n, dtype
+    # flags), visit vectors and moves against the oracle's after one get_action (player.py:128-147)
+    import torch
+    from alphafive_amd.engine import Engine, MODE_EXTERNAL, STATUS_MOVE_DONE, state_to_key
+    from test_gpu_parity import _compare_tree
+    ext = Engine(cfg, G, device=0, mode=MODE_EXTERNAL, training=True, seed=SEED, node_cap=4 * 800 + 64)   # (SELFPLAY's default; EXTERNAL's 32768 is sized for one game)
+    empty = oracle.board_to_state(np.zeros((S, S), np.int8))
+    ext.set_roots(np.arange(G), np.stack([state_to_key(empty, S)] * G), [-1] * G)
+    pol, val = torch.zeros((G, S * S), device="cuda"), torch.zeros((G,), device="cuda")
+    planes = torch.zeros((G, 3, S, S), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for t in range(1200):
+        ext.tick(pol.data_ptr(), val.data_ptr(), planes.data_ptr(), st)
+        p_, v_ = pseudonet.pseudonet_torch(planes, SALT, PEAK)
+        pol.copy_(p_), val.copy_(v_)
+        if t >= 800 and t % 16 == 0 and (ext.status(st) == STATUS_MOVE_DONE).all():
+            break
+    assert (ext.status(st) == STATUS_MOVE_DONE).all()
+    for g in (0, 1, 1234, 2047, G - 1):
+        orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
+                                  pseudo_salt=SALT, pseudo_peak=PEAK)
+        opol, oact, ovis = orc.get_action(empty, None)
+        act, pol_g, vis, _ = ext.move_result(g)
+        assert (vis == ovis).all() and (act // S, act % S) == oact
+        assert (pol_g.view(np.uint32) == opol.reshape(-1).view(np.uint32)).all()
+        seen, total = _compare_tree(ext.tree_dump(g), orc, S)
+        assert seen == total > 300
+    ext.close()
     ct_s, dumps_s = run(1024, 3072)                   # games 3072..4095 in their own engine
     for k in ("keys", "sum_n", "n"):
         assert (dumps[G - 1][k] == dumps_s[1023][k]).all()
     assert (dumps[G - 1]["w"].view(np.uint32) == dumps_s[1023]["w"].view(np.uint32)).all()
+
+
+def test_every_game_of_a_512_game_engine_equals_the_oracle():
+    """not a sample — every game of a 512-game engine at configs[1]'s settings (11x11, 500 / 642), first_game_id
+    3584 (the last 512 ids of the 4096-game bench engine; a game's tree depends on its id only), each first episode (and every
+    second one that exists) replayed by the C oracle on the host cores (tools/parity_sweep_fullsize.py; the 4096-game run of the
+    same sweep is profiles/r5_40)."""
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import parity_sweep_fullsize as sweep
+    rep = sweep.sweep(G=512, board=11, sims=500, upper=642, memo=False, first_game_id=3584)
+    print(rep)
+    assert rep["mismatches"] == 0, rep["first_mismatches"]
+    assert rep["episodes_compared_with_the_oracle"] >= 512 and rep["plies_compared"] > 512 * 9

@@ -167,8 +167,12 @@ def test_graph_loop_refuses_an_evaluator_of_ours_without_a_weight_version():
 
         def bind_outputs(self, p, v):
             pass
-    with pytest.raises(EngineError):
-        SelfPlayEngine(make_cfg(), 4, Anonymous(), device=0)
+    sp = SelfPlayEngine(make_cfg(), 4, Anonymous(), device=0)      # constructing is fine (eager tick() users: ADVICE r5) ...
+    with pytest.raises(EngineError, match="weights_version"):      # ... replaying launches over weights nobody versions is not
+        sp.run_ticks_graph(4)
+    sp.close()
+    with pytest.raises(EngineError, match="weights_version"):      # ... and neither is keeping their evaluations
+        SelfPlayEngine(make_cfg(), 4, Anonymous(), device=0, eval_memo=True)
 
 
 @pytest.mark.parametrize("board,goal,value_f64", [(15, 5, False), (7, 4, True)])

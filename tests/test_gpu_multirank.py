@@ -124,3 +124,29 @@ def test_rccl_branch_runs_on_the_device(tmp_path):
         d = json.load(f)
     assert d["backend"] == "nccl" and d["weights_same"] and d["moves"] == 1234.0
     assert len(d["ref"]) > 64 and d["got"] == d["ref"]            # same episodes, same order, bit for bit (crc of every record)
+
+
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """BASELINE configs[2]'s shape (8 ranks, games sharded by id, finished episodes gathered to rank 0) has
+    never met 8 devices; what can be de-risked on one is everything but the fabric: `python bench.py --gpus 8` spawning its own
+    eight ranks (sharing GPU 0, gloo), every rank seen by the group, rank 0 holding exactly the episodes each rank's device counter
+    says it finished — attributed to the right source rank, global game ids up to 8 G - 1 — and the pinned ring allocated once
+    (EpisodeGather raises on an overrun or a stale view, so rc 0 = it never happened)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", AF_BENCH_SHARE_GPU="1")
+    G = 256
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--games", str(G), "--board", "7", "--sims", "40",
+                        "--upper", "60", "--steps", "44", "--warmup", "4", "--no-cpu-baseline"], cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 8 * G) < 0.25 * 8 * G          # whole-job plies over the max-over-ranks time
+    _check_self_verifying_keys(d, 8, "gloo", "bench.py spawn_ranks")
+    c = d["config"]
+    assert c["episodes_gathered_by_source_rank"] == c["episodes_finished_by_rank_total"]   # per source rank, not just in total
+    assert min(c["episodes_gathered_by_source_rank"]) > 0
+    assert 7 * G <= c["max_global_game_id_gathered"] < 8 * G
+    assert c["gather_ring_allocations"] <= 24                                         # a few size classes x 3 ring slots, not one per step (48 steps)

@@ -40,10 +40,15 @@ def test_hip_net_matches_fp64_restatement_and_torch_reference():
     dv, dp = np.abs(v - v64), np.abs(p - p64)
     print("|dv| max %.3g  |dp| max %.3g (first 96: %.3g)" % (dv.max(), dp.max(), dp[:96].max()))
     assert dv.max() < 1e-5                             # BASELINE.json: value within 1e-5 (fp32) — on every position
-    # north_star binds the value only.  Probabilities: these random dense positions are unnatural inputs on which every fp32
-    # path (PyTorch-ROCm fp32 ops included) sits at the edge of 1e-5; measured 1.3e-5 over the 512, hence the honest bar:
-    assert dp[:96].max() < 1e-5 and dp.max() < 2e-5
+    # north_star binds the value only; the probabilities meet the same bar on all 512 positions (r6: 4.1e-6 measured)
+    assert dp.max() < 1e-5
     pt, vt = net.eval_torch(xt)                        # plain PyTorch fp32 reference (MIOpen picks Winograd)
+    # ... next to a measurement of what 24-bit arithmetic does on the same inputs: PyTorch's own fp32 evaluation against the same fp64
+    # restatement on the same 512 positions (the reference's class; r6: |dv| 6.8e-6, |dp| 3.5e-6 vs the kernel's 4.5e-6 / 4.1e-6) — the
+    # split-operand kernel is held to 2x of PyTorch-fp32's own worst error, per output
+    dpt, dvt = np.abs(pt.cpu().numpy() - p64), np.abs(vt.cpu().numpy() - v64)
+    print("PyTorch fp32 ops: |dv| max %.3g  |dp| max %.3g" % (dvt.max(), dpt.max()))
+    assert dp.max() <= 2.0 * dpt.max() and dv.max() <= 2.0 * dvt.max()
     assert (torch.from_numpy(v).cuda() - vt).abs().max().item() < 5e-5
     assert (torch.from_numpy(p).cuda() - pt).abs().max().item() < 5e-5
     assert np.allclose(p.sum(1), 1.0, atol=1e-5)

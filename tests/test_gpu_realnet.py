@@ -403,10 +403,25 @@ def test_deep_bf16_tower_kernel_matches_fp32_reference(blocks):
     for Bs in (1, 31, 33):                                       # ragged tails of the 32-position workgroups
         ps, vs = pv(x[:Bs].contiguous())
         assert torch.equal(ps, pd[:Bs]) and torch.equal(vs, vd[:Bs])
-    p, v = pv(x)                                                 # end to end through the evaluator seam
-    p2, v2 = net.eval_device(x)
+    p, v = (t.clone() for t in pv(x))                            # end to end through the evaluator seam
     assert p.shape == (B, 121) and torch.allclose(p.sum(1), torch.ones(B, device="cuda"), atol=1e-3)
-    assert (p - p2).abs().max().item() < 0.05 and (v - v2).abs().max().item() < 0.1
+    _assert_no_worse_than_torch_bf16(net, x, p, v)
+
+
+def _assert_no_worse_than_torch_bf16(net, x, p, v):
+    """Config 5 has no bit parity (bf16, random init); its bar: per output, the hand-written path's error against
+    an fp32 evaluation of the same bf16-valued weights is bounded by the error of the all-PyTorch bf16 path it replaces on the very
+    same positions — mean <= 1.25x, max <= 2x (+ one bf16 ulp of the output range) — instead of a fixed 0.05 / 0.1."""
+    import torch
+    p32, v32 = net.eval_device(x, dtype=torch.float32)
+    pt, vt = net.eval_device(x)
+    for name, got, ref, tor, ulp in (("policy", p, p32, pt, 2.0 ** -9 * float(p32.max())), ("value", v, v32, vt, 2.0 ** -9)):
+        e_hip, e_tor = (got.float() - ref).abs(), (tor.float() - ref).abs()
+        print("config 5 %s: |hip - fp32| mean %.3g max %.3g; |torch bf16 - fp32| mean %.3g max %.3g"
+              % (name, e_hip.mean().item(), e_hip.max().item(), e_tor.mean().item(), e_tor.max().item()))
+        assert e_hip.mean().item() <= 1.25 * e_tor.mean().item() + 1e-7, name
+        assert e_hip.max().item() <= 2.0 * e_tor.max().item() + ulp, name
+    assert p.argmax(1).eq(p32.argmax(1)).float().mean().item() >= pt.argmax(1).eq(p32.argmax(1)).float().mean().item() - 0.02
 
 
 @pytest.mark.parametrize("backend", ["hip", "torch"])
@@ -486,9 +501,8 @@ def test_config5_full_size_8192_games_on_the_bf16_tower():
     p, v = pv(sp.planes)
     assert p.shape == (G, 121) and torch.isfinite(p).all() and torch.isfinite(v).all()
     assert (p.sum(1) - 1).abs().max().item() < 1e-3 and v.abs().max().item() <= 1.0
-    # the hand-written path and the all-PyTorch bf16 path agree to bf16 accuracy on the very leaves of this batch
-    p2, v2 = net.eval_device(sp.planes)
-    assert (p - p2).abs().max().item() < 0.05 and (v - v2).abs().max().item() < 0.1
+    # on the very leaves of this batch the hand-written path is no further from fp32 arithmetic than the all-PyTorch bf16 path
+    _assert_no_worse_than_torch_bf16(net, sp.planes, p.clone(), v.clone())
     d = sp.engine.tree_dump(G - 1)
     assert ((d["sum_n"] - d["n"].sum(1) >= 0) & (d["sum_n"] - d["n"].sum(1) <= 1)).all()
     sp.close()
