@@ -255,7 +255,7 @@ struct F16sArgs {
     int gx0;              // af_conv_f16s_h15: workgroups (per blockIdx.y) of the half-0 class
     char* stash;          // af_conv_f16s_h15 -> af_corner_f16s: [board][slab of the stream][hi|lo][4 unit rows][pixels 208, 209, 223, 224] units
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses,
-                          // bit 3 (r6) slab loads and activation stores addressed modulo 128 positions (the upper bound of any
+                          // bit 3 (r6) activation stores / bit 12 slab loads addressed modulo 128 positions (the upper bound of any
                           // "intermediate tensors never leave the L2s" design: same instruction streams, no HBM behind them)
 };
 
@@ -339,7 +339,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     // 1.58 vs 1.55 ms per forward and moved |dp| from 6.0e-6 to 8.1e-6)
     auto slab_src = [&](int qq, int j) -> const char* {             // (qq: pseudo-position)
         const int p_ = (HV == 1 || HSEL >= 0) ? qq : qq / HV;
-        const int p = (A.abl & 8) ? (p_ & 127) : p_;     // abl bit 3 (profiling): activations addressed modulo 128 positions — every tensor an L2-resident ring
+        const int p = (A.abl & 0x1000) ? (p_ & 127) : p_;   // abl bit 12 (profiling): slab LOADS addressed modulo 128 positions (cache-resident ring); bit 3: the stores
         if (AF_F16S_MAIN_FIRST) return (j < NSM ? A.in + ((size_t)p * NSM + j) * kSlabH : A.in2 + ((size_t)p * NSP + (j - NSM)) * kSlabH) + wsrc;
         return (j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabH : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabH) + wsrc;
     };
@@ -1904,7 +1904,7 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
     a.hw = nullptr; a.hbias = nullptr; a.hx = nullptr; a.inv_scale_h = 1.0f;
     if (head >= 0) { a.hw = n->hcw[head]; a.hbias = n->hcb[head]; a.hx = n->hx[head]; a.inv_scale_h = n->hc_inv[head]; }
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
-    a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xff) | (li << 8); a.gx0 = 0; a.stash = n->stash;
+    a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xf0ff) | (li << 8); a.gx0 = 0; a.stash = n->stash;
     a.w2 = nullptr; a.bias2 = nullptr; a.inv_scale2 = 1.0f;
     a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
     return n->S == 11 ? launch_layer_g<Geo<11>>(n, st, li, a, head) : launch_layer_g<Geo<15>>(n, st, li, a, head);
@@ -1937,7 +1937,7 @@ static F16sArgs block_args(f16s_net* n, int li, const char* in, int batch, int h
     a.pw = n->pw[li]; a.inv_scale_p = n->inv_scale_p[li];
     a.w2 = n->w[li + 1]; a.bias2 = n->bias[li + 1]; a.inv_scale2 = n->inv_scale[li + 1];
     a.hw = n->hcw[head]; a.hbias = n->hcb[head]; a.hx = n->hx[head]; a.inv_scale_h = n->hc_inv[head];
-    a.batch = batch; a.abl = (n->abl & 0xff) | (li << 8); a.stash = n->stash;
+    a.batch = batch; a.abl = (n->abl & 0xf0ff) | (li << 8); a.stash = n->stash;
     return a;
 }
 
@@ -1989,7 +1989,7 @@ int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, fl
     F16sArgs P;
     memset(&P, 0, sizeof(P));
     P.in = n->o[1]; P.w = n->w[6]; P.bias = n->bias[6]; P.out = n->g[3]; P.inv_scale = n->inv_scale[6];
-    P.batch = batch; P.abl = (n->abl & 0xff) | (6 << 8); P.stash = n->stash; P.inv_scale2 = 1.0f; P.inv_scale_h = 1.0f;
+    P.batch = batch; P.abl = (n->abl & 0xf0ff) | (6 << 8); P.stash = n->stash; P.inv_scale2 = 1.0f; P.inv_scale_h = 1.0f;
     const F16sArgs V = block_args(n, 4, n->o[1], batch, 0);
     constexpr size_t ldsP = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 4 * 4096;                       // CT = 2, PS = 1, NTW = 4 (2 at small batches)
     constexpr size_t ldsV = Lds<G, 2>::kScrOff + (size_t)2 * 2 * 4096 * 2 + 36864;
@@ -2016,7 +2016,7 @@ int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, fl
         F16sArgs Q;
         memset(&Q, 0, sizeof(Q));
         Q.in = n->g[3]; Q.in2 = n->o[1]; Q.w = n->w[7]; Q.bias = n->bias[7]; Q.out = n->o[3]; Q.inv_scale = n->inv_scale[7];
-        Q.batch = batch; Q.abl = (n->abl & 0xff) | (7 << 8); Q.stash = n->stash; Q.inv_scale2 = 1.0f; Q.inv_scale_h = 1.0f;
+        Q.batch = batch; Q.abl = (n->abl & 0xf0ff) | (7 << 8); Q.stash = n->stash; Q.inv_scale2 = 1.0f; Q.inv_scale_h = 1.0f;
         const VfcArgs F = {n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b, n->hf_inv[0], value};
         constexpr size_t lds7 = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 4 * 4096;
         static std::atomic<uint64_t> attr7{0};
