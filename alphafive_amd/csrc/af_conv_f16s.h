@@ -27,6 +27,10 @@ int f16s_policy_branch(f16s_net* n, hipStream_t st, int batch, float* o5_dev, in
 // batches <= 8 on 11x11, heads fused: both branches on one stream ({policy conv1 || value block} in one launch): no side stream
 int f16s_small_branches_ok(const f16s_net* n, int batch);          // (abl bit 9 = the two-stream form, for A/B)
 int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, float* policy);
+// batches <= 8 on 11x11 (r6): the whole forward up to the policy head's input as ONE launch of dataflow roles + the policy dense layer
+int f16s_small_forward_ok(const f16s_net* n, int batch);           // (abl bit 11 = the multi-launch form, for A/B)
+int f16s_small_forward(f16s_net* n, hipStream_t st, const float* planes_dev, int batch, float* value, float* policy);
+int f16s_small_forward_error(f16s_net* n);                         // 1 if a role ever gave up waiting (synchronises)
 void f16s_set_ablation(f16s_net* n, int bits);
 int f16s_read_activation(f16s_net* n, int which, int batch, float* host);
 

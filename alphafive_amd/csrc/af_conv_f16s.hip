@@ -141,6 +141,22 @@ __device__ __forceinline__ void st16(void* gdst, const h8& v) {
 #endif
 }
 
+// Write-through ("sc1": agent scope) stores for data that another workgroup of the SAME launch reads (the roles of af_small_forward_f16s):
+// the line goes through this XCD's L2 to memory, so the consumer — on whatever XCD — needs no cache-wide release / acquire, only the
+// producer's `s_waitcnt vmcnt(0)` before it raises its flag (MI355X_MICROARCH.md price table: "publish-large", "handoff-flag").  By hand:
+// the compiler has no 16-byte scoped store; the s_nop covers the store-data hazard it would otherwise cover itself (the data
+// registers of a > 64-bit store must not be overwritten in the next wait states).
+template <class V16>
+__device__ __forceinline__ void st16_sc1(void* gdst, const V16& v) {
+    static_assert(sizeof(V16) == 16, "16-byte store");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+}
+template <class V8>
+__device__ __forceinline__ void st8_sc1(void* gdst, const V8& v) {
+    static_assert(sizeof(V8) == 8, "8-byte store");
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(gdst), "v"(v) : "memory");
+}
+
 // s_waitcnt vmcnt(n) for an n that is a constant once the surrounding loops are unrolled (the immediate is part of the instruction)
 __device__ __forceinline__ void wait_vmcnt(int n) {
 #define AF_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
@@ -180,6 +196,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" AF_F16S_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 #endif
+}
+
+// ... and the agent-scope form for slabs another workgroup of the same launch has just written (no nt on a hand-off: price table "nt-handoff")
+__device__ __forceinline__ void glds16_sc1(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 // ELU as max(x, min(exp(x), 1) - 1): one v_max_f32 instead of compare + select, and the clamp rides on v_exp_f32 (r3_44).  Against
@@ -227,6 +250,48 @@ __device__ unsigned long long g_f16s_wall[10][512][2];
 #define AF_TACC(slot, a, b)
 #endif
 
+// ---- roles of a single-launch forward (af_small_forward_f16s): counters in device memory, agent scope ----
+// The producer's stores must be visible to a consumer workgroup on ANOTHER XCD (the L2s are per XCD).  Everything a role hands on is
+// stored write-through (st16_sc1 / st8_sc1: agent scope per instruction); every wave drains its stores (vmcnt(0)), the workgroup
+// meets at a barrier, one thread bumps the counter.  The consumer polls the counter with agent-scope loads and reads the slabs with
+// agent-scope LDS-DMA (glds16_sc1) — df_wait_one — or, where it reads with ordinary loads (the dense layers), invalidates first
+// (df_wait_inv).  No cache-wide release anywhere: measured 64.9 -> 57 us per batch-1 forward with one, see profiles/r6_09 / r6_10.
+#ifdef AF_DF_TIMING
+// profiling build only (tools/probe_small_forward_timeline.py): per role (workgroup), the device-wide 100 MHz clock at 0 entry | 1 wait
+// satisfied | 2 body done (before the release) | 3 signalled | 4 exit
+__device__ unsigned long long g_df_wall[256][5];
+#define DF_T(i) if (threadIdx.x == 0 && blockIdx.x < 256) g_df_wall[blockIdx.x][i] = wall_clock64()
+#else
+#define DF_T(i)
+#endif
+__device__ __forceinline__ void df_signal(int* ctr) {
+    DF_T(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its write-through stores are acknowledged ...
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... then the counter
+    DF_T(3);
+}
+__device__ __forceinline__ void df_poll(const int* ctr, int need, int* err) {      // one lane; bounded (~seconds)
+    int it = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++it > (1 << 22)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+}
+__device__ __forceinline__ void df_wait_one(const int* ctr, int need, int* err) {
+    if (threadIdx.x == 0) df_poll(ctr, need, err);
+    DF_T(1);
+    __syncthreads();
+}
+__device__ __forceinline__ void df_wait_inv(const int* ctr, int need, int* err) {
+    if (threadIdx.x == 0) {
+        df_poll(ctr, need, err);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one invalidate for the workgroup (the L1 is the CU's, the L2 the XCD's) ...
+    }
+    DF_T(1);
+    __syncthreads();                                        // ... and nobody loads before it
+}
+
 struct F16sArgs {
     const char* in;       // S32, NSM slabs per position
     const char* in2;      // S32, NSP slabs per position (block input for the folded 1x1 projection)
@@ -254,6 +319,13 @@ struct F16sArgs {
     float inv_scale2;
     int gx0;              // af_conv_f16s_h15: workgroups (per blockIdx.y) of the half-0 class
     char* stash;          // af_conv_f16s_h15 -> af_corner_f16s: [board][slab of the stream][hi|lo][4 unit rows][pixels 208, 209, 223, 224] units
+    // DF = 1 (af_small_forward_f16s, r6): this body is one ROLE of a single-launch forward — it may start its slab stream only when
+    // df_wait[position] has reached df_need (the roles that write its input have signalled) and signals df_done[position] when its
+    // own stores are out; df_err is set if a wait gives up (a bounded spin: a lost role must not hang the device)
+    const int* df_wait;
+    int df_need;
+    int* df_done;
+    int* df_err;
     int abl;              // profiling: bit 0 no LDS-DMA after the first slabs, bit 1 no stores, bit 2 LDS-DMA from L2-hot addresses,
                           // bit 3 (r6) activation stores / bit 12 slab loads addressed modulo 128 positions (the upper bound of any
                           // "intermediate tensors never leave the L2s" design: same instruction streams, no HBM behind them)
@@ -268,8 +340,9 @@ struct F16sArgs {
 // af_corner_f16s) in one launch.
 // FU (r5): 1 / 2 = the block's SECOND convolution (32 -> 32, the value / policy branch's last one, with the fused head) runs in this kernel
 // too, on the first one's output kept in LDS — see "fused block" below.
-template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST, int WPE, int NTW, int HSEL, int FU = 0>
-__device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const int bx, const int gxw, const int tb = 0) {
+template <class G, int NSM, int NSP, int CT, int KS, int PS, bool OUT32, bool XACC, int PJ, int HD, int DIST, int WPE, int NTW, int HSEL, int FU = 0, int DF = 0>
+__device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const int bx, const int gxw, const int tb = 0,
+                                          const int by = (int)blockIdx.y, const int gy = (int)gridDim.y) {
     using L = Lay<G>;
     constexpr uint32_t kRowH = L::kRowH, kHalfH = L::kHalfH, kSlabH = L::kSlabH, kRowL = L::kRowL, kHalfL = L::kHalfL, kSlotL = L::kSlotL;
     constexpr uint32_t kZoff = Lds<G, DIST>::kZoff, kBiasOff = Lds<G, DIST>::kBiasOff, kScrOff = Lds<G, DIST>::kScrOff;
@@ -313,7 +386,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     // the middle is the only one whose role depends on the wave (a scalar branch in exchange / combine / epilogue).
     const int rot = KS == 2 ? ks * ((NT + 1) / 2) : 0;
 #define AF_OWN(jj) (KS == 1 || (jj) < NT / 2 || ((jj) < (NT + 1) / 2 && ks == 0))
-    const int ctg = (int)blockIdx.y * CT + ct, nso = (int)gridDim.y * CT;
+    const int ctg = by * CT + ct, nso = gy * CT;
     const uint32_t lds = (uint32_t)(uintptr_t)smem;
 
     // pseudo-position q = HALVES * position + half; this workgroup takes q0, q0 + gridDim.x, ... (gridDim.x is a multiple of
@@ -353,7 +426,8 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
         const uint32_t su = G::seg_unit(piece % G::PR) * 16u;
         const uint32_t offh = (uint32_t)(row >> 2) * kHalfH + (uint32_t)(row & 3) * kRowH + su;
         const uint32_t offl = (uint32_t)(row >> 2) * kHalfL + (uint32_t)(row & 3) * kRowL + su;
-        glds16(src + offh + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + offl)));
+        if (DF != 0) glds16_sc1(src + offh + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + offl)));
+        else glds16(src + offh + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + offl)));
     };
     // slab number `idx` of the stream this workgroup consumes (pseudo-positions q0, q0 + gridDim.x, ...; SPP slabs each)
     const int q0 = qpos;
@@ -366,11 +440,14 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     // Start-up (5-8 us of every launch, r2_39): the longest latencies first — the first kDist slabs (HBM -> LDS-DMA), then the
     // weights (L2) — and under them the LDS zeroing: only what LDS-DMA never writes (slack, the pad units 0..7 and 136..143 of
     // every unit row of every ring slot, the zero region), so it needs no ordering against the DMA
+    // (a role of the single-launch forward asks for its slabs later: when its producers have signalled — the weights do not wait)
+    if (DF == 0) {
 #pragma unroll
-    for (int d = 0; d < kDist; ++d) {
-        if ((uint32_t)d < nslabs) {
+        for (int d = 0; d < kDist; ++d) {
+            if ((uint32_t)d < nslabs) {
 #pragma unroll
-            for (int k = 0; k < NPC; ++k) dma_piece(stream_src(d), (uint32_t)d * kSlotL, k);
+                for (int k = 0; k < NPC; ++k) dma_piece(stream_src(d), (uint32_t)d * kSlotL, k);
+            }
         }
     }
 
@@ -424,7 +501,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
         }
     }
     for (uint32_t u = threadIdx.x; u < kSlotL / 16; u += 256) *reinterpret_cast<uint4*>(smem + kZoff + u * 16) = uint4{0, 0, 0, 0};
-    if (threadIdx.x < CT * 32) reinterpret_cast<float*>(smem + kBiasOff)[threadIdx.x] = A.bias[(int)blockIdx.y * CT * 32 + threadIdx.x];
+    if (threadIdx.x < CT * 32) reinterpret_cast<float*>(smem + kBiasOff)[threadIdx.x] = A.bias[by * CT * 32 + threadIdx.x];
     // lane geometry per pixel tile: LDS byte base of tap (0,0) in slot 0, zero-region twin, output unit
     uint32_t lb[NT], zb[NT];
     int pix[NT];
@@ -462,6 +539,16 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     if (HDS > 0) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) asm volatile("" : "+v"(HA[f]));
+    }
+    if (DF != 0) {
+        df_wait_one(A.df_wait + qpos, A.df_need, A.df_err);
+#pragma unroll
+        for (int d = 0; d < kDist; ++d) {
+            if ((uint32_t)d < nslabs) {
+#pragma unroll
+                for (int k = 0; k < NPC; ++k) dma_piece(stream_src(d), (uint32_t)d * kSlotL, k);
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -515,13 +602,23 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
                 if (kg == 0) {
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     char* o = A.hx + (size_t)pos * Hx<G>::kValPos + (uint32_t)pix[jj] * 8u;
-                    *reinterpret_cast<h4*>(o) = h4{uh[0], uh[1], uh[2], uh[3]};
-                    *reinterpret_cast<h4*>(o + Hx<G>::kValLo) = h4{ul[0], ul[1], ul[2], ul[3]};
+                    if (DF != 0) {
+                        st8_sc1(o, h4{uh[0], uh[1], uh[2], uh[3]});
+                        st8_sc1(o + Hx<G>::kValLo, h4{ul[0], ul[1], ul[2], ul[3]});
+                    } else {
+                        *reinterpret_cast<h4*>(o) = h4{uh[0], uh[1], uh[2], uh[3]};
+                        *reinterpret_cast<h4*>(o + Hx<G>::kValLo) = h4{ul[0], ul[1], ul[2], ul[3]};
+                    }
                 }
             } else {
                 char* o = A.hx + (size_t)pos * Hx<G>::kPolPos + (uint32_t)pix[jj] * 32u + (uint32_t)kg * 16u;
-                *reinterpret_cast<h8*>(o) = h8{uh[0], uh[1], uh[2], uh[3], uh[4], uh[5], uh[6], uh[7]};
-                *reinterpret_cast<h8*>(o + Hx<G>::kPolLo) = h8{ul[0], ul[1], ul[2], ul[3], ul[4], ul[5], ul[6], ul[7]};
+                if (DF != 0) {
+                    st16_sc1(o, h8{uh[0], uh[1], uh[2], uh[3], uh[4], uh[5], uh[6], uh[7]});
+                    st16_sc1(o + Hx<G>::kPolLo, h8{ul[0], ul[1], ul[2], ul[3], ul[4], ul[5], ul[6], ul[7]});
+                } else {
+                    *reinterpret_cast<h8*>(o) = h8{uh[0], uh[1], uh[2], uh[3], uh[4], uh[5], uh[6], uh[7]};
+                    *reinterpret_cast<h8*>(o + Hx<G>::kPolLo) = h8{ul[0], ul[1], ul[2], ul[3], ul[4], ul[5], ul[6], ul[7]};
+                }
             }
         }
       }
@@ -594,7 +691,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
                 bL[jj] = edgeL[jj] ? zb[jj] : bC[jj];
                 bR[jj] = edgeR[jj] ? zb[jj] : bC[jj];
             }
-            if (HSEL == 1 && wv == (j & 3) && blockIdx.y == 0 && lane < 32) {
+            if (HSEL == 1 && wv == (j & 3) && by == 0 && lane < 32) {
                 // The corner pixel's operands, while the slab is in LDS (r5): the four on-board taps of pixel 224 are pixels 208, 209,
                 // 223, 224 = window units 128, 129, 143, 144 of each of the slab's 8 unit rows — 32 units of 16 bytes, copied to a compact
                 // buffer that af_corner_f16s reads as contiguous 512-byte rows (read from the S32 tensor they are 3 cache lines of 128
@@ -806,8 +903,8 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
                             *reinterpret_cast<h8*>(og + hf * kRowL + kHalfL) = lo;
                         }
                     } else if (ok[jj] && !(A.abl & 2)) {      // (tile 3 always has valid lanes: the two stores are always issued)
-                        st16(o + hf * kRowH, hi);
-                        st16(o + hf * kRowH + kHalfH, lo);
+                        if (DF != 0) { st16_sc1(o + hf * kRowH, hi); st16_sc1(o + hf * kRowH + kHalfH, lo); }
+                        else { st16(o + hf * kRowH, hi); st16(o + hf * kRowH + kHalfH, lo); }
                     }
                 }
             }
@@ -870,6 +967,7 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
         }
 #endif
     }
+    if (DF != 0) df_signal(A.df_done + q0);
 #ifdef AF_F16S_TIMING
     if (lane == 0) {
         tacc[0] = tacc[5] - tacc[1] - tacc[2] - tacc[3] - tacc[4];
@@ -1130,14 +1228,21 @@ __global__ __launch_bounds__(256) void af_stem_f16s(const float* __restrict__ pl
 // fragment (pixel n, group (cin, ky)) is the 8-wide input window starting at column x-2 of row y+ky-2, pre-expanded into
 // LDS once per position as 3 x 15 x 11 entries of 8 fp16 ("im2row"): one aligned ds_read_b128.  The planes are 0/1 —
 // exact in fp16 — so only the weights are split: two MFMAs per k-step.  One wave = one pixel tile x the 32 couts.
-template <class G>
-__global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict__ planes, const uint4* __restrict__ w /*[8][hi|lo][64]*/,
-                                                         const float* __restrict__ bias, float inv_scale, char* __restrict__ out, int batch) {
+template <class G> struct StemLds {       // LDS of the stem body: the im2row entries and the zero-bordered fp16 image
+    static constexpr int SR = G::S + 4, IW = G::S + 5;
+    static constexpr int kEnt = 3 * SR * G::S + 1, kImg = 3 * SR * IW;
+    static constexpr uint32_t kImgOff = (uint32_t)((kEnt * 16 + 255) / 256 * 256), kBytes = kImgOff + (uint32_t)kImg * 2u;
+};
+// (the body: workgroup bx of gx walks the positions bx, bx + gx, ...; ent / img: StemLds<G>::kEnt uint4 and kImg fp16 of LDS)
+template <class G, bool SC1 = false>
+__device__ __forceinline__ void f16s_stem_body(const float* __restrict__ planes, const uint4* __restrict__ w /*[8][hi|lo][64]*/,
+                                               const float* __restrict__ bias, float inv_scale, char* __restrict__ out, int batch,
+                                               const int bx, const int gx, uint4* ent, _Float16* img) {
     constexpr int S = G::S, NPIX = G::NPIX, SR = S + 4, IW = S + 5;          // image: rows -2..S+1, IW columns (-2 .. S+2)
     constexpr int NPL = 3 * NPIX, NLD = (NPL + 255) / 256;                    // plane elements per position / per thread
     constexpr int NTL = (NPIX + 31) / 32, NRND = (NTL + 3) / 4;               // pixel tiles per position / tile rounds per wave
     constexpr uint32_t kRowH = Lay<G>::kRowH, kHalfH = Lay<G>::kHalfH, kSlabH = Lay<G>::kSlabH;
-    __shared__ __attribute__((aligned(16))) uint4 ent[3 * SR * S + 1];       // entry (cin, yy, x) = window x-2..x+5 of row yy-2
+    // entry (cin, yy, x) of ent = window x-2..x+5 of row yy-2
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     h8 W[16];
@@ -1153,7 +1258,6 @@ __global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict
     // registers that were loaded one position ahead, and the im2row entries are built from that image — the build used to read
     // the planes from global memory five scattered words per entry inside the loop (11x11: 44 -> 22 us per 4096 positions; same
     // values).  15x15 (r3): the same kernel, two rounds of four pixel tiles per wave (the VALU stem took 125 us).
-    __shared__ _Float16 img[3 * SR * IW];
     for (int i = threadIdx.x; i < 3 * SR * IW; i += 256) img[i] = (_Float16)0.0f;
     auto img_at = [](int i) -> int { const int c = i / NPIX, p = i - c * NPIX, y = p / S, x = p - y * S; return (c * SR + y + 2) * IW + x + 2; };
     int at[NLD];
@@ -1163,15 +1267,15 @@ __global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict
         const int i = (int)threadIdx.x + 256 * q;
         at[q] = img_at(i < NPL ? i : 0);
         nx[q] = 0.0f;
-        if (i < NPL && (int)blockIdx.x < batch) nx[q] = planes[(size_t)blockIdx.x * NPL + i];
+        if (i < NPL && bx < batch) nx[q] = planes[(size_t)bx * NPL + i];
     }
-    for (int pos = blockIdx.x; pos < batch; pos += gridDim.x) {
+    for (int pos = bx; pos < batch; pos += gx) {
         __syncthreads();                                                     // the previous position's reads are done
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
             if ((int)threadIdx.x + 256 * q < NPL) img[at[q]] = (_Float16)nx[q];
-        if (pos + (int)gridDim.x < batch) {                                  // next position's planes: in flight under this one
-            const float* pl = planes + (size_t)(pos + gridDim.x) * NPL;
+        if (pos + gx < batch) {                                              // next position's planes: in flight under this one
+            const float* pl = planes + (size_t)(pos + gx) * NPL;
 #pragma unroll
             for (int q = 0; q < NLD; ++q)
                 if ((int)threadIdx.x + 256 * q < NPL) nx[q] = pl[threadIdx.x + 256 * q];
@@ -1215,12 +1319,23 @@ __global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict
                     lo[e] = (_Float16)(f - (float)h);
                 }
                 if (ok) {
-                    *reinterpret_cast<h8*>(o + hf * kRowH) = hi;
-                    *reinterpret_cast<h8*>(o + hf * kRowH + kHalfH) = lo;
+                    if (SC1) { st16_sc1(o + hf * kRowH, hi); st16_sc1(o + hf * kRowH + kHalfH, lo); }
+                    else {
+                        *reinterpret_cast<h8*>(o + hf * kRowH) = hi;
+                        *reinterpret_cast<h8*>(o + hf * kRowH + kHalfH) = lo;
+                    }
                 }
             }
         }
     }
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void af_stem_mfma_f16s(const float* __restrict__ planes, const uint4* __restrict__ w, const float* __restrict__ bias,
+                                                         float inv_scale, char* __restrict__ out, int batch) {
+    __shared__ __attribute__((aligned(16))) uint4 ent[StemLds<G>::kEnt];
+    __shared__ _Float16 img[StemLds<G>::kImg];
+    f16s_stem_body<G>(planes, w, bias, inv_scale, out, batch, (int)blockIdx.x, (int)gridDim.x, ent, img);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------------
@@ -1319,6 +1434,204 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int gp = P.gx0, id = (int)blockIdx.x;
     if (id < gp) f16s_body<G, 2, 4, 2, 2, 1, false, true, 0, 0, kDist, 1, 4, -1>(P, smem, id, gp);
     else f16s_vfc_body<G>(V.xv, V.a, V.b1, V.w2, V.b2, V.inv_scale, V.value, P.batch, id - gp);
+}
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// The whole small-batch forward (<= 8 positions, 11x11) up to the policy head's input as ONE launch (r6; VERDICT r5 item 6: the drop-in
+// Player evaluates one leaf per simulation, and its tick was 9 dependent launches whose per-launch start-up — weights into 512 registers
+// per wave out of L2, LDS zeroing, ramp — cost more than their MFMAs: 93 us per tick, profiles/r5_20).  Every workgroup of the nine
+// launches becomes a ROLE of this one, indexed in dependency order (stem, block 1, block 2, {policy conv1 | value block}, {policy conv2 |
+// value dense}, block 5): all roles are dispatched at once, load their weights at once, and a role starts its slab stream when the
+// roles that write its input have signalled (F16sArgs::df_*; per-position counters in device memory, agent-scope release / acquire
+// because producer and consumer may sit on different XCDs).  A role only ever waits for roles of LOWER workgroup index, and
+// workgroups are dispatched in index order, so the launch cannot deadlock whatever else occupies the device; the waits are bounded
+// all the same (df_err).  The role bodies are the multi-launch path's bodies with the same template arguments, tile bases and
+// operands: the same MFMAs in the same order — bit-identical outputs (tests/test_gpu_net.py, af_net_tune(7, 2048) = the launches).
+// The last workgroup to finish zeroes the counters for the next launch.
+// ----------------------------------------------------------------------------------------------------------------------------
+constexpr int kDfStem = 0, kDfL0 = 8, kDfL1 = 16, kDfL2 = 24, kDfL3 = 32, kDfP = 40, kDfV = 48, kDfQ = 56, kDfB5 = 64, kDfPF = 72, kDfFin = 73, kDfErr = 74, kDfWords = 75;
+struct SmallFwdArgs {
+    const float* planes; const uint4* stem_w; const float* stem_b; float stem_inv; char* f0;
+    F16sArgs L0, L1, L2, L3, P, V, Q, B5;
+    VfcArgs F;
+    // the policy head's dense layer as two roles (K halves): input, packed A fragments, bias, 1 / weight scale, output, and the
+    // fp32 scratch through which K half 1 hands its partial sums to K half 0 ([tile 4][float4 4][lane 64])
+    const char* xp; const uint4* pfa; const float* pfb; float pf_inv; float* policy; float* pfx;
+    int* df;
+    int batch;
+};
+
+// The policy head's dense layer + softmax (af_policy_fc_f16s) for <= 8 positions as two ROLES of the single-launch forward: role kh =
+// K half kh (pixels 64 kh .. 64 kh + 63), wave mt = logit tile mt — the batched kernel's eight waves, four per workgroup.  What a role
+// does BEFORE its input exists is the point: a wave's first 32 k-steps of dense weights (256 registers) are loaded while the trunk is
+// still running, the other 32 stream in behind the MFMA chain.  Per (kh, mt) the same MFMAs on the same operands in the same order
+// (step ascending; A_hi B_hi, A_hi B_lo, A_lo B_hi into one accumulator; steps past the board add exact zeros), K half 0 + K half 1,
+// the same scale / bias expression and the same 16-threads-per-position softmax tree: bit-identical to af_policy_fc_f16s.
+template <class G>
+__device__ __forceinline__ void f16s_pfc_role(const SmallFwdArgs& S, const int kh, char* smem) {
+    constexpr int NPIX = G::NPIX, HXP = Hx<G>::HXP, NLT = Hx<G>::NLT, LW = 32 * NLT, LWP = LW + 1, NS = HXP / 2, RD = 32;
+    static_assert(NLT == 4 && NS == 64, "the role form of the policy head is written for 11x11 (one logit tile per wave)");
+    const int nb = S.batch, lane = threadIdx.x & 63, n = lane & 31, kg = lane >> 5;
+    const int mt = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int* const df = S.df;
+    const int step0 = NS * kh, nstep = NPIX - step0 < NS ? NPIX - step0 : NS;
+    const uint4* ap = S.pfa + ((size_t)step0 * NLT + mt) * 128 + lane;          // + step * NLT * 128 (+ 64: the lo halves)
+    uint4 ring[RD][2];
+#pragma unroll
+    for (int q = 0; q < RD; ++q) {
+        const int st_ = q < nstep ? q : nstep - 1;
+        ring[q][0] = ap[(size_t)st_ * NLT * 128];
+        ring[q][1] = ap[(size_t)st_ * NLT * 128 + 64];
+    }
+    float bj[16];                       // this lane's 16 logit biases: loaded before the wait (the acquire below empties the caches)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int j = 32 * mt + 16 * kg + r; bj[r] = S.pfb[j < NPIX ? j : 0]; }
+    // the weights of steps 32..63 cannot be held yet (the ring is full): touch them, so that the refills under the MFMA chain are L2
+    // hits on this XCD instead of 256 KB per workgroup out of memory (one dword per lane and fragment: every line of the rows)
+    {
+        unsigned sink = 0;
+#pragma unroll
+        for (int q = RD; q < NS; ++q) {
+            const int st_ = q < nstep ? q : nstep - 1;
+            sink ^= reinterpret_cast<const unsigned*>(ap + (size_t)st_ * NLT * 128)[0] ^ reinterpret_cast<const unsigned*>(ap + (size_t)st_ * NLT * 128 + 64)[0];
+        }
+        asm volatile("" : : "v"(sink));
+    }
+    if (threadIdx.x == 0) {
+        for (int p = 0; p < nb; ++p) df_poll(df + kDfB5 + p, 1, df + kDfErr);
+    }
+    DF_T(1);
+    __syncthreads();
+    // this K half of every position's input -> LDS ([position][hi|lo][64 pixels][16 channels] fp16, positions kXS bytes apart so that
+    // the lanes of different positions fall into different banks) by agent-scope LDS-DMA (the producer stored write-through: no
+    // invalidate, the weights stay where they are): 1 KB per instruction, 4 per position; then the B fragments are ds_read_b128 and the
+    // only vector-memory traffic under the MFMA chain is the weight ring 32 steps ahead
+    constexpr uint32_t kXS = 2u * NS * 32u + 16u;
+    for (int c = mt; c < nb * 4; c += 4) {                                     // chunk c = (position, half, 1-KB part)
+        const int pp = c >> 2, hl = (c >> 1) & 1, part = c & 1;
+        glds16_sc1(S.xp + (size_t)pp * Hx<G>::kPolPos + (uint32_t)hl * Hx<G>::kPolLo + (uint32_t)step0 * 32u + (uint32_t)part * 1024u + (uint32_t)lane * 16u,
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)smem + (uint32_t)pp * kXS + (uint32_t)hl * (NS * 32u) + (uint32_t)part * 1024u)));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int pq = n < nb ? n : nb - 1;                                        // (column n of the MFMA = position n; the columns past the batch repeat the last one)
+    const char* xb = smem + (uint32_t)pq * kXS + (uint32_t)kg * 16u;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    h8 bh = *reinterpret_cast<const h8*>(xb), bl = *reinterpret_cast<const h8*>(xb + NS * 32);
+#pragma unroll
+    for (int st_ = 0; st_ < NS; ++st_) {
+        h8 ah, al, nbh = bh, nbl = bl;
+        __builtin_memcpy(&ah, &ring[st_ % RD][0], 16); __builtin_memcpy(&al, &ring[st_ % RD][1], 16);
+        if (st_ + 1 < NS) {                                                    // the next step's B fragments: their LDS latency sits under this step's MFMAs
+            nbh = *reinterpret_cast<const h8*>(xb + (st_ + 1) * 32);
+            nbl = *reinterpret_cast<const h8*>(xb + NS * 32 + (st_ + 1) * 32);
+        }
+        if (st_ + RD < NS) {
+            const int pf = st_ + RD < nstep ? st_ + RD : nstep - 1;
+            ring[st_ % RD][0] = ap[(size_t)pf * NLT * 128];
+            ring[st_ % RD][1] = ap[(size_t)pf * NLT * 128 + 64];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        // keep the ring a ring: hipcc otherwise sinks every refill to its use 32 steps later (one memory round trip per step: the role
+        // took 8.8 us instead of 4, profiles/r6_11)
+        if (st_ + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads (the next step's B fragments)
+        if (st_ + RD < NS) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); // 2 VMEM reads (step + RD's A fragments)
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                     // 3 MFMA
+        bh = nbh; bl = nbl;
+    }
+    __syncthreads();                                                           // (the staging area becomes the logit array below)
+    f32x4* const px = reinterpret_cast<f32x4*>(S.pfx) + (size_t)mt * 4 * 64 + lane;
+    if (kh == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st16_sc1(px + q * 64, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+        df_signal(df + kDfPF);
+        return;
+    }
+    df_wait_inv(df + kDfPF, 1, df + kDfErr);
+    float* Lg = reinterpret_cast<float*>(smem);                                // [32 positions][LWP]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 o = px[q * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e, j = 32 * mt + 16 * kg + r;
+            Lg[n * LWP + j] = j < NPIX ? (acc[r] + o[e]) * S.pf_inv + bj[r] : -3.0e38f;
+        }
+    }
+    __syncthreads();
+    const int p = (int)threadIdx.x >> 4, sub = (int)threadIdx.x & 15;         // 16 threads per position (256 threads: positions 0..15 >= the batch)
+    constexpr int NV = LW / 16;
+    float v[NV], mx = -3.0e38f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { v[q] = Lg[p * LWP + sub + 16 * q]; mx = fmaxf(mx, v[q]); }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { v[q] = (sub + 16 * q) < NPIX ? expf(v[q] - mx) : 0.0f; sum += v[q]; }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (p < nb) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int j = sub + 16 * q;
+            if (j < NPIX) S.policy[(size_t)p * NPIX + j] = v[q] / sum;
+        }
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_small_forward_f16s(SmallFwdArgs S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nb = S.batch;
+    int id = (int)blockIdx.x;
+    int* const df = S.df;
+    DF_T(0);
+    if (id < nb) {
+        DF_T(1);
+        f16s_stem_body<G, true>(S.planes, S.stem_w, S.stem_b, S.stem_inv, S.f0, nb, id, nb, reinterpret_cast<uint4*>(smem),
+                          reinterpret_cast<_Float16*>(smem + StemLds<G>::kImgOff));
+        df_signal(df + kDfStem + id);
+    } else if ((id -= nb) < 2 * nb) {                 // bone/block1 conv1: a position's two pixel-tile pairs on two workgroups
+        f16s_body<G, 1, 0, 2, 1, 2, false, false, 0, 0, 1, 1, 1, -1, 0, 1>(S.L0, smem, id % nb, nb, (id / nb) * 2, 0, 1);
+    } else if ((id -= 2 * nb) < 2 * nb) {             // bone/block1 conv2 + projection
+        f16s_body<G, 2, 1, 2, 1, 2, false, true, 0, 0, kDist, 1, 1, -1, 0, 1>(S.L1, smem, id % nb, nb, (id / nb) * 2, 0, 1);
+    } else if ((id -= 2 * nb) < 4 * nb) {             // bone/block2 conv1: one pixel tile per workgroup
+        f16s_body<G, 2, 0, 4, 1, 1, false, false, 0, 0, kDist, 1, 1, -1, 0, 1>(S.L2, smem, id % nb, nb, id / nb, 0, 1);
+    } else if ((id -= 4 * nb) < 4 * nb) {             // bone/block2 conv2 + projection: 2 cout-tile pairs x 2 pixel-tile pairs
+        const int r = id / nb;
+        f16s_body<G, 4, 2, 2, 2, 1, false, false, 0, 0, kDist, 1, 2, -1, 0, 1>(S.L3, smem, id % nb, nb, (r >> 1) * 2, r & 1, 2);
+    } else if ((id -= 4 * nb) < 3 * nb) {             // policy/block4 conv1 (two workgroups) | the whole value block (one)
+        if (id < 2 * nb) f16s_body<G, 4, 0, 2, 2, 1, false, false, 0, 0, kDist, 1, 2, -1, 0, 1>(S.P, smem, id % nb, nb, (id / nb) * 2, 0, 1);
+        else f16s_body<G, 4, 0, 1, 2, 2, false, false, 1, 0, 2, 1, 2, -1, 1, 1>(S.V, smem, id - 2 * nb, nb, 0, 0, 1);
+    } else if ((id -= 3 * nb) < 2 * nb + 1) {         // policy/block4 conv2 + projection (two workgroups) | the value head's dense layers (one for all)
+        if (id < 2 * nb) {
+            f16s_body<G, 2, 4, 2, 2, 1, false, true, 0, 0, kDist, 1, 2, -1, 0, 1>(S.Q, smem, id % nb, nb, (id / nb) * 2, 0, 1);
+        } else {
+            if (threadIdx.x == 0) {
+                for (int p = 0; p < nb; ++p) df_poll(df + kDfV + p, 1, df + kDfErr);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            DF_T(1);
+            __syncthreads();
+            f16s_vfc_body<G>(S.F.xv, S.F.a, S.F.b1, S.F.w2, S.F.b2, S.F.inv_scale, S.F.value, nb, 0);
+        }
+    } else if ((id -= 2 * nb + 1) < nb) {             // policy/block5 (fused block + the policy head's 1x1 convolution)
+        f16s_body<G, 2, 0, 1, 1, 4, false, true, 1, 0, 2, 1, 1, -1, 2, 1>(S.B5, smem, id, nb, 0, 0, 1);
+    } else {                                          // the policy head's dense layer: K half 1, then K half 0 (which waits for it)
+        f16s_pfc_role<G>(S, id - nb == 0 ? 1 : 0, smem);
+    }
+    __syncthreads();
+    DF_T(4);
+    if (threadIdx.x == 0) {
+        if (__hip_atomic_fetch_add(df + kDfFin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+            for (int i = 0; i <= kDfFin; ++i) __hip_atomic_store(df + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (kDfErr stays: the host reads it)
+        }
+    }
 }
 
 // policy: fc 16*S*S -> S*S, softmax.  Workgroup = 32 positions x 8 waves = (MT tiles of 32 logits: mt, mt + 4, ...) x (half of K):
@@ -1714,6 +2027,8 @@ struct f16s_net {
     float *hcb[2] = {}, *hfb[2] = {}, *v2w = nullptr, *v2b = nullptr;
     float hc_inv[2] = {}, hf_inv[2] = {};
     char* hx[2] = {};
+    int* df = nullptr;            // af_small_forward_f16s: role counters (kDfWords ints, zero between launches)
+    float* pfx = nullptr;         // ... and the policy head's K-half hand-over (16 KB)
     char* stash = nullptr;        // 15x15: corner operands of the layer in flight (af_conv_f16s_h15 -> af_corner_f16s), 6 slabs x 512 B per board
     int abl = 0;
 };
@@ -1790,6 +2105,16 @@ int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const
         FS_HIP_OK(hipMalloc(&q, (size_t)max_batch * 6 * 512));
         n->allocs.push_back(q);
         n->stash = (char*)q;
+    }
+    if (!rc) {
+        void* q = nullptr;
+        FS_HIP_OK(hipMalloc(&q, kDfWords * sizeof(int)));
+        FS_HIP_OK(hipMemset(q, 0, kDfWords * sizeof(int)));
+        n->allocs.push_back(q);
+        n->df = (int*)q;
+        FS_HIP_OK(hipMalloc(&q, 4 * 4 * 64 * 16));
+        n->allocs.push_back(q);
+        n->pfx = (float*)q;
     }
     if (!rc) rc = act(&n->f0, 32);
     for (int b = 0; b < 5 && !rc; ++b) {
@@ -2040,6 +2365,65 @@ int f16s_small_branches(f16s_net* n, hipStream_t st, int batch, float* value, fl
     FS_HIP_OK(hipGetLastError());
     return rc;
 }
+
+// The single-launch small-batch forward (af_small_forward_f16s) + the policy head's dense layer.
+// (abl bit 11 = the multi-launch form, for A/B; it also yields to the older A/B bits of the small-batch path)
+int f16s_small_forward_ok(const f16s_net* n, int batch) {
+    return n && n->S == 11 && batch >= 1 && batch <= kSmallBatch && !(n->abl & (16 | 32 | 128 | 256 | 512 | 2048));
+}
+static F16sArgs layer_args(f16s_net* n, int li, const char* in, const char* in2, char* out, int batch) {
+    F16sArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.inv_scale = n->inv_scale[li]; a.batch = batch;
+    a.abl = (n->abl & 0xf0ff) | (li << 8); a.stash = n->stash; a.inv_scale2 = 1.0f; a.inv_scale_h = 1.0f;
+    a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
+    return a;
+}
+int f16s_small_forward(f16s_net* n, hipStream_t st, const float* planes, int batch, float* value, float* policy) {
+    if (!f16s_small_forward_ok(n, batch) || !planes || !value || !policy) return -1;
+    using G = Geo<11>;
+    SmallFwdArgs S;
+    memset(&S, 0, sizeof(S));
+    S.planes = planes; S.stem_w = n->stem_wm; S.stem_b = n->stem_b; S.stem_inv = n->stem_inv_scale; S.f0 = n->f0;
+    S.df = n->df; S.batch = batch;
+    auto role = [&](F16sArgs a, int wait, int need, int done) { a.df_wait = n->df + wait; a.df_need = need; a.df_done = n->df + done; a.df_err = n->df + kDfErr; return a; };
+    S.L0 = role(layer_args(n, 0, n->f0, nullptr, n->g[0], batch), kDfStem, 1, kDfL0);
+    S.L1 = role(layer_args(n, 1, n->g[0], n->f0, n->o[0], batch), kDfL0, 2, kDfL1);
+    S.L2 = role(layer_args(n, 2, n->o[0], nullptr, n->g[1], batch), kDfL1, 2, kDfL2);
+    S.L3 = role(layer_args(n, 3, n->g[1], n->o[0], n->o[1], batch), kDfL2, 4, kDfL3);
+    S.P = role(layer_args(n, 6, n->o[1], nullptr, n->g[3], batch), kDfL3, 4, kDfP);
+    S.P.pw = nullptr; S.P.pbuf = nullptr;
+    S.V = role(block_args(n, 4, n->o[1], batch, 0), kDfL3, 4, kDfV);
+    S.Q = role(layer_args(n, 7, n->g[3], n->o[1], n->o[3], batch), kDfP, 2, kDfQ);
+    S.Q.pw = nullptr; S.Q.pbuf = nullptr;
+    S.B5 = role(block_args(n, 8, n->o[3], batch, 1), kDfQ, 2, kDfB5);
+    S.F = VfcArgs{n->hx[0], n->hfw[0], n->hfb[0], n->v2w, n->v2b, n->hf_inv[0], value};
+    constexpr size_t ldsC = Lds<G, kDist>::kScrOff + (size_t)2 * 1 * 4 * 4096;                 // the k-split layers (CT = 2, PS = 1)
+    constexpr size_t ldsV = Lds<G, 2>::kScrOff + (size_t)2 * 2 * 4096 * 2 + 36864;           // the value block
+    constexpr size_t ldsB = Lds<G, 2>::kScrOff + Lay<G>::kSlotL + 36864;                     // block 5
+    constexpr size_t lds = std::max(std::max(ldsC, ldsV), std::max(ldsB, (size_t)StemLds<G>::kBytes));
+    static_assert(lds + 256 <= 160 * 1024, "LDS budget (dynamic + the value head's static reduction buffer)");
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    FS_HIP_OK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
+        FS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_small_forward_f16s<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_devs.fetch_or(bit, std::memory_order_relaxed);
+    }
+    S.xp = n->hx[1]; S.pfa = n->hfw[1]; S.pfb = n->hfb[1]; S.pf_inv = n->hf_inv[1]; S.policy = policy; S.pfx = n->pfx;
+    hipLaunchKernelGGL(af_small_forward_f16s<G>, dim3(19 * batch + 3), dim3(256), lds, st, S);
+    FS_HIP_OK(hipGetLastError());
+    return 0;
+}
+// 1 if a role of af_small_forward_f16s ever gave up waiting (synchronises; tests)
+int f16s_small_forward_error(f16s_net* n) {
+    if (!n || !n->df) return -1;
+    int e = 0;
+    FS_HIP_OK(hipDeviceSynchronize());
+    FS_HIP_OK(hipMemcpy(&e, n->df + kDfErr, sizeof(int), hipMemcpyDeviceToHost));
+    return e;
+}
 // (abl bit 9: the two-stream form at small batches; bit 10: at full batch — for A/B)
 int f16s_small_branches_ok(const f16s_net* n, int batch) {
     if (!n || n->S != 11 || (n->abl & 256)) return 0;
@@ -2070,6 +2454,13 @@ int f16s_read_activation(f16s_net* n, int which, int batch, float* host) {
     return C;
 }
 
+#ifdef AF_DF_TIMING
+extern "C" int af_df_debug_wall(unsigned long long* host) {
+    FS_HIP_OK(hipDeviceSynchronize());
+    FS_HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_df_wall), sizeof(unsigned long long) * 256 * 5));
+    return 0;
+}
+#endif
 #ifdef AF_F16S_TIMING
 extern "C" int af_f16s_debug_cycles(unsigned long long* host) {
     FS_HIP_OK(hipDeviceSynchronize());

@@ -1298,6 +1298,11 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     const bool fhead = split16 && g_fhead;                 // heads fused into the split-operand path
     if (split16) {
         f16s_set_ablation(n->f16s, g_f16s_abl);
+        if (fhead && f16s_small_forward_ok(n->f16s, batch)) {
+            // <= 8 positions on 11x11: one launch of dataflow roles instead of nine dependent launches (af_conv_f16s.hip, r6)
+            if (f16s_small_forward(n->f16s, st, planes, batch, value, policy)) return AF_NET_ERR_HIP;
+            return AF_NET_OK;
+        }
         if (f16s_trunk(n->f16s, st, planes, batch)) return AF_NET_ERR_HIP;
     } else {
         hipLaunchKernelGGL(af_stem_conv, dim3(batch), dim3(256), 0, st, planes, n->stem_w, n->stem_b, f0, S, WP, PP);
@@ -1443,6 +1448,11 @@ int af_net_debug_activation(af_net* n, int32_t which, int32_t batch, float* host
     if (!n || !host_out || !n->f16s) return AF_NET_ERR_ARG;
     const int c = f16s_read_activation(n->f16s, which, batch, host_out);
     return c < 0 ? AF_NET_ERR_ARG : c;
+}
+
+int af_net_small_forward_error(af_net* n) {
+    if (!n || !n->f16s) return AF_NET_ERR_ARG;
+    return f16s_small_forward_error(n->f16s);
 }
 
 int64_t af_net_flops_per_position(const af_net* n) {

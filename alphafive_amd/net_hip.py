@@ -34,6 +34,7 @@ def lib():
         L.af_net_forward.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
         L.af_net_flops_per_position.argtypes = [vp]
         L.af_net_flops_per_position.restype = C.c_int64
+        L.af_net_small_forward_error.argtypes = [vp]
         L.af_net_strerror.argtypes = [C.c_int]
         L.af_net_strerror.restype = C.c_char_p
         _lib = L
@@ -86,6 +87,10 @@ class HipNet(object):
         _check(lib().af_net_forward(self._h, stream, planes.data_ptr(), B, self.policy.data_ptr(), self.value.data_ptr()),
                "af_net_forward")
         return self.policy[:B], self.value[:B]
+
+    def small_forward_error(self):
+        """1 if a role of the single-launch small-batch forward ever gave up waiting for its producers (synchronises)."""
+        return int(lib().af_net_small_forward_error(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -66,6 +66,12 @@ int af_net_tune(int32_t key, int32_t value);
  * positions of the last forward, as fp32 [batch][C][121] on the host.  Returns the channel count C or <0. */
 int af_net_debug_activation(af_net* n, int32_t which, int32_t batch, float* host_out);
 
+/* Batches of at most 8 positions on 11x11 (what genData/player.py:186-202 asks for: one leaf per simulation) run as ONE launch of
+ * dataflow roles + the policy head's dense layer (csrc/af_conv_f16s.hip: af_small_forward_f16s; af_net_tune(7, 2048) = the nine
+ * dependent launches, for A/B).  A role's wait for its producers is bounded; this returns 1 if any wait ever gave up (the outputs
+ * of that forward are then undefined), 0 if none did, <0 without the split-operand path.  Synchronises the device. */
+int af_net_small_forward_error(af_net* n);
+
 /* FLOPs (2*MAC) of one position's forward pass, as executed (direct convolution). */
 int64_t af_net_flops_per_position(const af_net* n);
 const char* af_net_strerror(int code);

@@ -168,3 +168,59 @@ def test_round5_launch_variants_are_bit_identical(S, B, bits):
     assert torch.equal(p_new, p_old) and torch.equal(v_new, v_old)
     p64, v64 = net_fp64.forward(net.variables, _positions(S, B, seed=B)[:8])
     assert np.abs(v_new[:8].cpu().numpy() - v64).max() < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 8])
+def test_single_launch_small_batch_forward_is_bit_identical_to_the_launch_sequence(B):
+    """r6: <= 8 positions on 11x11 run as ONE launch of dataflow roles (af_small_forward_f16s: every workgroup of the
+    nine dependent launches becomes a role that waits for its producers' counters) + the policy dense layer.  Same role bodies, same
+    operands: policy and value equal the launch sequence's (af_net_tune(7, 2048)) bit for bit, run after run (the counters are
+    re-armed by the last role out), no wait ever gives up, and a batch evaluated alone equals its slots inside a large batch."""
+    import torch
+    from alphafive_amd import net_hip
+    from alphafive_amd.network import ResNet
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    h = net_hip.HipNet(net.variables, 11, 64, net.device)
+    x = _positions(11, 64, seed=77 + B)
+    xt = torch.from_numpy(x).cuda()
+    pb, vb = (t.clone() for t in h(xt))                       # the batched kernels (64 positions)
+    try:
+        net_hip.tune(7, 2048)
+        p_old, v_old = (t.clone() for t in h(xt[:B].contiguous()))
+    finally:
+        net_hip.tune(7, 0)
+    for rep in range(20):                                     # back to back: the counters re-arm
+        p_new, v_new = (t.clone() for t in h(xt[rep % 3:rep % 3 + B].contiguous()))
+        if rep % 3 == 0:
+            assert torch.equal(p_new, p_old) and torch.equal(v_new, v_old), rep
+        assert torch.equal(p_new, pb[rep % 3:rep % 3 + B]) and torch.equal(v_new, vb[rep % 3:rep % 3 + B]), rep
+    assert h.small_forward_error() == 0
+    p64, v64 = net_fp64.forward(net.variables, x[:B])
+    assert np.abs(v_old.cpu().numpy() - v64).max() < 1e-5
+    h.close()
+
+
+def test_single_launch_small_batch_forward_inside_a_hip_graph():
+    """The Player replays 16 x (tick + forward) as a HIP graph: the single launch must capture and replay (its counters live in
+    device memory and are re-armed on the device)."""
+    import torch
+    from alphafive_amd import net_hip
+    from alphafive_amd.network import ResNet
+    net = ResNet(11, device="cuda")
+    net.load_npz(W)
+    h = net_hip.HipNet(net.variables, 11, 8, net.device)
+    xt = torch.from_numpy(_positions(11, 3, seed=5)).cuda()
+    p0, v0 = (t.clone() for t in h(xt))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(16):
+            h(xt)
+    for _ in range(5):
+        h.policy.zero_(), h.value.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(h.policy[:3], p0) and torch.equal(h.value[:3], v0)
+    assert h.small_forward_error() == 0
+    h.close()
