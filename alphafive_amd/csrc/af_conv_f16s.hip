@@ -108,9 +108,8 @@ constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB
 #ifndef AF_F16S_NT_STORE
 #define AF_F16S_NT_STORE 0
 #endif
-#ifndef AF_F16S_M0CLOB
-#define AF_F16S_M0CLOB 0          // A/B (r3_43): m0 declared clobbered by the LDS-DMA asm instead of saved / restored around it: -0.2 %, but hipcc
-#endif                            // warns that a clobber of the reserved m0 "may not be preserved": not adopted
+// (A/B record r3_43, removed from the source in r6: m0 declared clobbered by the LDS-DMA asm instead of saved / restored around it:
+//  -0.2 %, but hipcc warns that a clobber of the reserved m0 "may not be preserved")
 // (r3_43, rejected: requesting past the end of the slab stream — the last position again — so that no branch surrounds the LDS-DMA
 //  instructions: +1 %, the surplus loads cost more than the branches)
 #ifndef AF_F16S_APIN
@@ -188,14 +187,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 #else
 #define AF_F16S_LOAD_POLICY " sc0 nt"
 #endif
-#if AF_F16S_M0CLOB
-    (void)keep;                 // A/B: m0 declared clobbered instead of saved and restored around the instruction
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" AF_F16S_LOAD_POLICY
-                 : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
-#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" AF_F16S_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-#endif
 }
 
 // ... and the agent-scope form for slabs another workgroup of the same launch has just written (no nt on a hand-off: price table "nt-handoff")
@@ -208,15 +201,8 @@ __device__ __forceinline__ void glds16_sc1(const void* gsrc, uint32_t lds_dst) {
 // ELU as max(x, min(exp(x), 1) - 1): one v_max_f32 instead of compare + select, and the clamp rides on v_exp_f32 (r3_44).  Against
 // x > 0 ? x : exp(x) - 1 the result differs only for -3e-4 < x < 0, where the rounding of v_exp_f32 can put exp(x) - 1 an ulp of 1.0
 // (6e-8) below x and the max then returns x — itself within x^2/2 < 5e-8 of the true value: |dv| / |dp| against the fp64 restatement
-// are unchanged to all printed digits (profiles/r3_44, r3_54: AF_F16S_ELU_OLD = 1 reproduces the earlier outputs bit for bit).
+// are unchanged to all printed digits (profiles/r3_44, r3_54; the compare / select form was removed from the source in r6).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifndef AF_F16S_ELU_OLD
-#define AF_F16S_ELU_OLD 0
-#endif
-#if AF_F16S_ELU_OLD
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
-__device__ __forceinline__ f32x2 elu2(f32x2 x) { return f32x2{elu1(x.x), elu1(x.y)}; }
-#else
 __device__ __forceinline__ float elu1(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
     return fmaxf(x, fminf(fmaxf(e, 0.0f), 1.0f) - 1.0f);
@@ -231,7 +217,6 @@ __device__ __forceinline__ f32x2 elu2(f32x2 x) {
     const f32x2 em1 = e - 1.0f;
     return f32x2{fmaxf(x.x, em1.x), fmaxf(x.y, em1.y)};
 }
-#endif
 
 #ifndef AF_F16S_XCD_SWIZZLE
 #define AF_F16S_XCD_SWIZZLE 1

@@ -130,24 +130,8 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // half: v_permlane32_swap / v_permlane16_swap (gfx950) hand every lane its own and its partner's value as the pair (r[0], r[1]) in one
 // order or the other — fp64 addition is commutative, so r[0] + r[1] has the bits of own + partner; row_ror:8 is lane ^ 8 inside a
 // 16-lane row; after that step the values are 8-periodic, so row_ror:4 delivers the value of lane ^ 4; quad permutes do ^ 2 and ^ 1.
-#ifndef AF_TICK_SUM_DPP
-#define AF_TICK_SUM_DPP 1
-#endif
-#ifndef AF_TICK_NOISE_PASS0
-#define AF_TICK_NOISE_PASS0 1
-#endif
-#ifndef AF_TICK_NOISE_PAIR
-#define AF_TICK_NOISE_PAIR 0      // r5 A/B record (profiles/r5_03_tick_ab.txt): clean-up rounds with two attempts side by side — same bits, +5.5 % per launch: off
-#endif
-#ifndef AF_TICK_PAIR_FROM
-#define AF_TICK_PAIR_FROM 4
-#endif
-#ifndef AF_TICK_ROOT_TERM
-#define AF_TICK_ROOT_TERM 1       // r5: depth-0 terminal test: two-sided for EXTERNAL-mode roots, none in self-play (see the descent)
-#endif
-#ifndef AF_TICK_TERM_LAST
-#define AF_TICK_TERM_LAST 1
-#endif
+// (A/B records, removed from the source in r6: clean-up rounds with two attempts side by side — same bits, +5.5 % per launch,
+//  profiles/r5_03_tick_ab.txt; round 0 of a lane's cells one after the other instead of side by side — r4_15)
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -155,7 +139,6 @@ __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
 }
 __device__ __forceinline__ double wave_sum_f64_tree(double acc) {
-#if AF_TICK_SUM_DPP
     {
         const int lo = __double2loint(acc), hi = __double2hiint(acc);
         const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
@@ -171,11 +154,6 @@ __device__ __forceinline__ double wave_sum_f64_tree(double acc) {
     acc = acc + dpp_f64<0x4E>(acc);       // quad_perm [2,3,0,1]
     acc = acc + dpp_f64<0xB1>(acc);       // quad_perm [1,0,3,2]
     return acc;
-#else
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
-    return acc;
-#endif
 }
 
 template <int KW>
@@ -888,10 +866,10 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
             // line — utils.py:199-235 returns (True, 1.0) there, so the scan is the two-sided one (the one-sided scan let
             // such a root be searched).  Inside a descent: through the last move only.
             bool term;
-            if (AF_TICK_ROOT_TERM && depth == 0)
+            if (depth == 0)
                 term = P.mode == AF_MODE_EXTERNAL ? (bool)terminal_test<KW, false>(P, cm, ctb, &tv) : false;
             else
-                term = (AF_TICK_TERM_LAST && depth > 0 && P.goal <= 8) ? (bool)terminal_through_last<KW>(P, cm, ctb, last, inv_s16, lane, &tv)
+                term = (depth > 0 && P.goal <= 8) ? (bool)terminal_through_last<KW>(P, cm, ctb, last, inv_s16, lane, &tv)
                                                                        : (bool)terminal_test<KW, true>(P, cm, ctb, &tv);
             if (term) {                                                                                                   // :213-217
                 backup(depth, tv, 0);
@@ -1001,7 +979,6 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                     uint32_t todo = 0;
 #pragma unroll
                     for (int k = 0; k < KW; ++k) { dd[k] = 0.0; todo |= ((legal[k] >> lane) & 1ull) ? (1u << k) : 0u; }
-#if AF_TICK_NOISE_PASS0
                     // Round 0 of EVERY cell of the lane first, side by side (two independent dependency chains: the kernel's slow
                     // waves run alone on their SIMD and wait on instruction latency, not on issue slots), then the rejected cells
                     // (10 % of them) one at a time as before: the wave needs 1 double + ~2 single rounds instead of ~4 singles, at the
@@ -1024,61 +1001,6 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                     ++tk_myit;
 #endif
                     todo = pend;
-#if AF_TICK_NOISE_PAIR
-                    // (AF_TICK_NOISE_PAIR = 2: only from the AF_TICK_PAIR_FROM-th select of a launch on — the waves that run that many selects
-                    //  are the launch's tail, alone on their SIMD, where the second chain is free; both loops give the same bits)
-                    if (AF_TICK_NOISE_PAIR == 1 || work >= AF_TICK_PAIR_FROM) {
-                    // Clean-up rounds, two attempts side by side (r5).  A rejected cell continues with attempts 1, 2, ... of ITS counter
-                    // sequence (attempt a = words 2(a&1), 2(a&1)+1 of block a>>1), so whatever is evaluated speculatively, the variate is
-                    // the first accepted attempt = af_gamma_lt1's.  Slot A = the lane's first pending cell's next attempt; slot B = the
-                    // second pending cell's next attempt if the lane has one, else the SAME cell's following attempt (used only if A is
-                    // rejected).  Two independent dependency chains per iteration — what paid in round 0 — and the wave needs
-                    // ~1.2 clean-up iterations instead of ~3 (r4_15: the launch's slow waves spend 2/3 of a select here).  MEASURED
-                    // (profiles/r5_03_tick_ab.txt, steady-state mix, same digest): 0.1226-0.1234 ms per launch against 0.1162 — the
-                    // second chain doubles the instructions of iterations in which ~10 of 64 lanes are active, and in the bulk of a
-                    // launch four waves share a SIMD's issue slots; the latency it saves the lone waves of the tail is worth less.  Each slot
-                    // makes its own Philox block (no block is carried from one iteration to the next: the 8 registers of a cache cost
-                    // scratch at the kernel's 128-register budget, a block costs ~65 of an iteration's ~600 instructions).
-                    uint32_t itc[KW];
-#pragma unroll
-                    for (int q = 0; q < KW; ++q) itc[q] = 1u;
-                    while (todo) {
-#ifdef AF_TICK_TIMING
-                        ++tk_myit;
-#endif
-                        const int ka = __builtin_ctz(todo);
-                        const uint32_t rest = todo & (todo - 1u);
-                        const bool two = rest != 0u;
-                        const int kb = two ? __builtin_ctz(rest) : ka;
-                        uint32_t ia = 1u, ib = 1u;
-#pragma unroll
-                        for (int q = 0; q < KW; ++q) {
-                            ia = q == ka ? itc[q] : ia;
-                            ib = q == kb ? itc[q] : ib;
-                        }
-                        ib = two ? ib : ia + 1u;
-                        const af_u32x4 ra = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * ka), ia >> 1, k0, k1);
-                        const af_u32x4 rb = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * kb), ib >> 1, k0, k1);
-                        float XA, XB;
-                        const int okA = af_gamma_round(a_, inv_a, one_m_a, (ia & 1u) ? ra.v[2] : ra.v[0], (ia & 1u) ? ra.v[3] : ra.v[1], &XA);
-                        const int okB = af_gamma_round(a_, inv_a, one_m_a, (ib & 1u) ? rb.v[2] : rb.v[0], (ib & 1u) ? rb.v[3] : rb.v[1], &XB);
-                        // af_gamma_lt1: an attempt is accepted, or the variate is 0 after attempt 0xFFFF
-                        const bool endA = okA || ia == 0xFFFFu;
-                        const bool endB = okB || ib == 0xFFFFu;
-                        const double XAd = okA ? (double)XA : 0.0, XBd = okB ? (double)XB : 0.0;
-                        // one pending cell: B is that cell's next attempt and counts only if A was rejected
-                        const bool doneA = endA || (!two && endB);
-                        const double vA = endA ? XAd : XBd;
-                        const bool doneB = two && endB;
-#pragma unroll
-                        for (int q = 0; q < KW; ++q) {
-                            if (q == ka) { dd[q] = doneA ? vA : dd[q]; itc[q] = two ? ia + 1u : ia + 2u; }
-                            if (two && q == kb) { dd[q] = doneB ? XBd : dd[q]; itc[q] = ib + 1u; }
-                        }
-                        todo &= ~((doneA ? (1u << ka) : 0u) | (doneB ? (1u << kb) : 0u));
-                    }
-                    } else
-#endif
                     {
                     uint32_t it = 1;
                     af_u32x4 r = rk[0];
@@ -1106,31 +1028,6 @@ __global__ __launch_bounds__(64, AF_TICK_MIN_WAVES) void af_tick_kernel(EnginePa
                         }
                     }
                     }
-#else
-                    uint32_t it = 0;
-                    af_u32x4 r;
-                    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
-                    while (todo) {
-#ifdef AF_TICK_TIMING
-                        ++tk_myit;
-#endif
-                        const int k = __builtin_ctz(todo);
-                        // one Philox block feeds two rounds of a cell (a lane stays on its cell until it accepts)
-                        if ((it & 1u) == 0u) r = af_philox4x32(sel_id, episode, (AF_STREAM_GAMMA << 24) | (uint32_t)(lane + 64 * k), it >> 1, k0, k1);
-                        const uint32_t wu = (it & 1u) ? r.v[2] : r.v[0], wv = (it & 1u) ? r.v[3] : r.v[1];
-                        float X;
-                        const int ok = af_gamma_round(a_, inv_a, one_m_a, wu, wv, &X);
-                        if (ok || it == 0xFFFFu) {
-                            const double Xd = ok ? (double)X : 0.0;
-#pragma unroll
-                            for (int q = 0; q < KW; ++q) dd[q] = q == k ? Xd : dd[q];
-                            todo &= todo - 1u;
-                            it = 0;
-                        } else {
-                            ++it;
-                        }
-                    }
-#endif
                 }
 #ifdef AF_TICK_TIMING
                 tk[12] += (unsigned long long)wave_max_i32(tk_myit);       // the wave's iterations = its slowest lane's

@@ -70,14 +70,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 #endif
 }
 
-// ... with the sc0 sc1 bits: the load is served by L2, not by a line the CU's vector L1 may still hold from an earlier layer
-// (af_tower_persist: a workgroup re-reads what its own waves stored a layer ago; measured r3_19: the bits cost nothing)
-__device__ __forceinline__ void glds16c(const void* gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc0 sc1 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
 // ELU as max(x, min(exp(x), 1) - 1): x > 0 ? x : exp(x) - 1 with one v_max_f32 instead of compare + select and the clamp riding on
 // v_exp_f32 (r3_44).  exp(x) - 1 > x for x < 0 and the clamped exponential is exactly 1 for x >= 0; only for -3e-4 < x < 0 can the
 // rounding of v_exp_f32 put exp(x) - 1 below x, and the max then returns x, within 5e-8 of the true value (see af_conv_f16s.hip)
@@ -132,15 +124,10 @@ __device__ unsigned long long g_tower_cyc[2][256][4][5];
 #else
 #define TT(v)
 #endif
-// One convolution layer over this workgroup's positions.  CHAINED (af_tower_persist): called layer after layer inside one launch —
-// the layer starts once every wave's stores of the previous one have been acknowledged, and stages its planes with L1-bypassing loads.
-template <bool PROJ, int DEPTH, bool CHAINED>
+// One convolution layer over this workgroup's positions.
+template <bool PROJ, int DEPTH>
 __device__ __forceinline__ void tower_layer(const TowerArgs& A, char* smem) {
     constexpr int NS = PROJ ? 80 : 72;
-    if (CHAINED) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
     const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem + kLds0;
@@ -148,7 +135,7 @@ __device__ __forceinline__ void tower_layer(const TowerArgs& A, char* smem) {
     auto stage_round = [&](const char* src, int pos, uint32_t off, int r) {   // 4 KB piece r of a position's plane -> LDS
         const char* gp = src + (size_t)pos * kPlaneB + threadIdx.x * 16u + r * 4096;
         const uint32_t ld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + off + wv * 1024u + r * 4096u));
-        if (CHAINED) glds16c(gp, ld); else glds16(gp, ld);
+        glds16(gp, ld);
     };
     auto stage = [&](const char* src, int pos, uint32_t off) {          // one position's plane -> LDS at byte offset off
 #pragma unroll
@@ -292,52 +279,19 @@ __device__ __forceinline__ void tower_layer(const TowerArgs& A, char* smem) {
 #endif
     }
 #ifdef AF_TOWER_TIMING
-    if (!CHAINED && lane == 0 && blockIdx.x < 256) for (int q = 0; q < 5; ++q) g_tower_cyc[PROJ ? 1 : 0][blockIdx.x][wv][q] = tacc[q];
+    if (lane == 0 && blockIdx.x < 256) for (int q = 0; q < 5; ++q) g_tower_cyc[PROJ ? 1 : 0][blockIdx.x][wv][q] = tacc[q];
 #endif
 }
 
 template <bool PROJ, int DEPTH>
 __global__ __launch_bounds__(256, 1) void af_tower_conv(TowerArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];         // [256 B][g0][g1]([h])
-    tower_layer<PROJ, DEPTH, false>(A, smem);
+    tower_layer<PROJ, DEPTH>(A, smem);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// af_tower_persist (r4, A/B: af_tower_tune(3, 4)): the whole residual tower as ONE launch.  The 16 convolutions of the 8 blocks are
-// identical in shape and a convolution never looks outside its position, so a workgroup that keeps the same 32 positions from layer
-// to layer depends on no other workgroup: no grid-wide barrier, no flags — between two layers a wave waits for its own stores, the
-// workgroup meets at a barrier, the weight registers are reloaded (L2) and the position loop starts again on the other activation
-// buffer (staged with L1-bypassing loads).  Same arithmetic, same order: bit-identical to 16 x af_tower_conv.
-// MEASURED (profiles/r4_36): 4.217 ms per 8192-position pass against 4.198 (16 launches) — removing fifteen launches, their start-ups
-// and their device-wide barriers buys nothing: the phase stamps (r4_35) put 98 % of a position's MFMA loop at the MFMA issue rate and the
-// rest in the epilogue (2.3 k of 11.8 k cycles per position, VALU-bound: ~9 issue slots per output element), none of it between
-// positions or layers; the workgroups that finish a layer late are the same ones in every layer (XCD, profiles/r4_03), so a chain
-// without barriers ends with them just the same.  This is the single-launch experiment VERDICT r3 asked for, on the part of the
-// code base where it is easiest (no cout-split layer, one layer shape); the default stays 16 launches.
-struct PersistArgs {
-    char* x;                     // C8 bf16: block input / output (in place)
-    char* g;                     // C8 bf16: the block's intermediate
-    const uint4* const* w1;      // [blocks] A fragments of the first / second convolution (pack_tower)
-    const uint4* const* w2;
-    const float* const* b1;      // [blocks] biases
-    const float* const* b2;
-    int blocks, batch;
-    char* dump;
-};
-
-template <int D1, int D2>
-__global__ __launch_bounds__(256, 1) void af_tower_persist(PersistArgs P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    for (int b = 0; b < P.blocks; ++b) {
-        TowerArgs a;
-        a.batch = P.batch; a.abl = 0; a.dump = P.dump;
-        a.in = P.x; a.in2 = nullptr; a.w = P.w1[b]; a.bias = P.b1[b]; a.out = P.g;
-        if (b == 0) tower_layer<false, D1, false>(a, smem);            // (its input comes from an earlier launch)
-        else tower_layer<false, D1, true>(a, smem);
-        a.in = P.g; a.in2 = P.x; a.w = P.w2[b]; a.bias = P.b2[b]; a.out = P.x;
-        tower_layer<true, D2, true>(a, smem);
-    }
-}
+// (r4 A/B record, removed from the source in r6: the whole tower as ONE launch — af_tower_persist, a workgroup keeping its 32 positions
+//  from layer to layer with no grid barrier — was bit-identical and bought nothing: 4.217 vs 4.198 ms per 8192-position pass,
+//  profiles/r4_36; 98 % of a position's MFMA loop already runs at the MFMA issue rate and the late workgroups are the same in every layer)
 
 // ---------------------------------------------------------------------------------------------------------------
 // af_tower_conv3<PROJ, DEPTH> (r4): af_tower_conv with its epilogue taken off the critical path.  In af_tower_conv a position is
@@ -578,218 +532,8 @@ __global__ __launch_bounds__(256, 1) void af_tower_conv3(TowerArgs A) {
         for (int k = 0; k < kEpiK; ++k) epi_stage(2, c, k, o_prev);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// af_tower_conv2<PROJ> (r2): the same convolution on the structure of af_conv_f16s.hip (the 11x11 fp32-class net), single
-// bf16 product.  A workgroup = 4 waves = 2 k-halves (wave ks takes channels 16ks..16ks+15 of every 32-channel slab) x 2
-// pixel pairs (tiles 2ps, 2ps+1); blockIdx.y picks a pair of cout tiles (64 couts): every wave multiplies BOTH cout
-// tiles with each B fragment it reads (half the LDS reads per MFMA of af_tower_conv) and keeps its 72 [80] weight
-// fragments in registers.  The input streams through LDS in 32-channel slabs (9 KB: rows 4s..4s+3 of the C8 position;
-// only units 8..135 of a row are copied, the pad units of a slot are zeroed once) on a 5-slot ring by LDS-DMA, prefetch
-// distance 3, counted vmcnt; fragments are double buffered per item (k-step x tap) and prefetched across slab
-// boundaries (the barrier publishing slab t+1 sits in front of the last item of slab t).  The k-halves exchange one pixel
-// tile each through LDS per position and each finishes one (bias, ELU, bf16, 16-byte stores).
-constexpr uint32_t kRowB = kPIX * 16u, kSlab2 = 4u * kRowB;               // 2,304 / 9,216 bytes
-constexpr int kDist2 = 3, kRing2 = kDist2 + 2;
-constexpr uint32_t kZ2 = kLds0 + kRing2 * kSlab2, kBias2 = kZ2 + 1024u, kScr2 = kBias2 + 256u, kLds2Total = kScr2 + 2u * 16384u;
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
-    bf16x8 x, y;
-    __builtin_memcpy(&x, &a, 16);
-    __builtin_memcpy(&y, &b, 16);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
-}
-
-template <bool PROJ>
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void af_tower_conv2(TowerArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NSP = PROJ ? 4 : 0, SPP = NSP + 4, NIT = NSP + 36;
-    const int lane = threadIdx.x & 63, kg = lane >> 5, nn = lane & 31;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ks = wv & 1, ps = wv >> 1, g = (int)blockIdx.y;
-    const uint32_t lds = (uint32_t)(uintptr_t)smem;
-    int pos = blockIdx.x;
-    if (pos >= A.batch) return;
-    const int pos0 = pos;
-
-    auto slab_src = [&](int p, int j) -> const char* {
-        return j < NSP ? A.in2 + (size_t)p * kPlaneB + (uint32_t)j * kSlab2 : A.in + (size_t)p * kPlaneB + (uint32_t)(j - NSP) * kSlab2;
-    };
-    auto dma_piece = [&](const char* src, uint32_t slot_off, int q) {      // piece wv + 4q (q = 0,1) of the slab's 8
-        const int piece = wv + 4 * q;
-        const uint32_t off = (uint32_t)(piece >> 1) * kRowB + (8u + 64u * (piece & 1)) * 16u;
-        glds16(src + off + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds + kLds0 + slot_off + off)));
-    };
-    const uint32_t nslabs = (uint32_t)((A.batch - pos0 + (int)gridDim.x - 1) / (int)gridDim.x) * SPP;
-
-    for (uint32_t u = threadIdx.x; u < kBias2 / 16; u += 256) *reinterpret_cast<uint4*>(smem + u * 16) = uint4{0, 0, 0, 0};
-    __syncthreads();
-    if (threadIdx.x < 64) reinterpret_cast<float*>(smem + kBias2)[threadIdx.x] = A.bias[64 * g + threadIdx.x];
-#pragma unroll
-    for (int d = 0; d < kDist2; ++d) {
-        if ((uint32_t)d < nslabs) {
-            const int p = pos0 + (d / SPP) * (int)gridDim.x;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) dma_piece(slab_src(p, d % SPP), (uint32_t)d * kSlab2, q);
-        }
-    }
-    u32x4 W[2 * NIT];                                                    // [item][cout tile of the pair]
-    {
-        const u32x4* wp = reinterpret_cast<const u32x4*>(A.w) + ((size_t)(g * 2 + ks) * (2 * NIT)) * 64 + lane;
-#pragma unroll
-        for (int f = 0; f < 2 * NIT; ++f) W[f] = wp[f * 64];
-    }
-    uint32_t lb[2], zb[2];
-    int pix[2];
-    bool ok[2], edgeL[2], edgeR[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int n = 32 * (2 * ps + jj) + nn;
-        ok[jj] = n < kNPIX;
-        const int nc = ok[jj] ? n : 0;
-        pix[jj] = nc;
-        const int x = nc % kS;
-        edgeL[jj] = x == 0; edgeR[jj] = x == kS - 1;
-        lb[jj] = kLds0 + (uint32_t)(2 * ks + kg) * kRowB + (uint32_t)(nc * 16) - 16u;     // tap (ky,kx) reads unit (nc - 1) + 11 ky + kx
-        zb[jj] = kZ2 + (lb[jj] & 255u);
-    }
-#pragma unroll
-    for (int f = 0; f < 2 * NIT; ++f) asm volatile("" : "+v"(W[f]));
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    auto rd = [](const char* sm, bool proj, int it, uint32_t c_, uint32_t l_, uint32_t r_) -> u32x4 {
-        const int tap = proj ? 4 : it, ky = tap / 3, kx = tap % 3;
-        const uint32_t base = kx == 0 ? l_ : (kx == 2 ? r_ : c_);
-        return *reinterpret_cast<const u32x4*>(sm + base + (uint32_t)(ky * kS + kx) * 16u);
-    };
-    uint32_t t = 0, cur = 0u, nxd = (uint32_t)kDist2 * kSlab2;
-    u32x4 fr[2][2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const uint32_t c_ = lb[jj], l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_;
-        fr[0][jj] = rd(smem, PROJ, 0, c_, l_, r_);
-    }
-    for (; pos < A.batch; pos += gridDim.x) {
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][jj][r] = 0.0f;
-#pragma clang loop unroll(full)
-        for (int j = 0; j < SPP; ++j) {
-            const bool proj = j < NSP, nproj = (j + 1) % SPP < NSP;
-            const int NI = proj ? 1 : 9;
-            const int ibase = proj ? j : NSP + (j - NSP) * 9;
-            const int npos = pos + ((j + kDist2) / SPP) * (int)gridDim.x;
-            const bool more = npos < A.batch && !(A.abl & 1);
-            const char* nsrc = slab_src(more ? npos : pos, (j + kDist2) % SPP);
-            const uint32_t nx1 = cur + kSlab2 == kRing2 * kSlab2 ? 0u : cur + kSlab2;
-            uint32_t bC[2], bL[2], bR[2];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                bC[jj] = lb[jj] + cur;
-                bL[jj] = edgeL[jj] ? zb[jj] : bC[jj];
-                bR[jj] = edgeR[jj] ? zb[jj] : bC[jj];
-            }
-#pragma clang loop unroll(full)
-            for (int it = 0; it < NI; ++it) {
-                const int b = (ibase + it) & 1;
-                if (it + 1 < NI) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) fr[b ^ 1][jj] = rd(smem, proj, it + 1, bC[jj], bL[jj], bR[jj]);
-                } else {
-                    // last item of slab t: slab t+1 has landed for every wave (in flight: kDist-2 whole slabs + this slab's pieces)
-                    if (more) {
-                        if (NI > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kDist2 - 2) + 2) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kDist2 - 2)) : "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    __builtin_amdgcn_s_barrier();
-                    if (t + 1 < nslabs) {
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const uint32_t c_ = lb[jj] + nx1, l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_;
-                            fr[b ^ 1][jj] = rd(smem, nproj, 0, c_, l_, r_);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) acc[m][jj] = mfma_bf16(W[2 * (ibase + it) + m], fr[b][jj], acc[m][jj]);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if (more) {
-                    if (it < NI - 1 && it < 2) dma_piece(nsrc, nxd, it);
-                    if (it == NI - 1) {
-#pragma unroll
-                        for (int q = (NI - 1 < 2 ? NI - 1 : 2); q < 2; ++q) dma_piece(nsrc, nxd, q);
-                    }
-                }
-            }
-            ++t;
-            cur = nx1;
-            nxd = nxd + kSlab2 == kRing2 * kSlab2 ? 0u : nxd + kSlab2;
-        }
-        // the two k-halves of a pixel pair: wave ks finishes pixel tile jj == ks and hands the other one over
-        {
-            char* scr = smem + kScr2 + (uint32_t)ps * 16384u;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    if (jj != ks) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 v = {acc[m][jj][4 * q], acc[m][jj][4 * q + 1], acc[m][jj][4 * q + 2], acc[m][jj][4 * q + 3]};
-                            *reinterpret_cast<float4*>(scr + (uint32_t)((m * 2 + jj) * 4 + q) * 1024u + lane * 16u) = v;
-                        }
-                    }
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    if (jj == ks) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 v = *reinterpret_cast<const float4*>(scr + (uint32_t)((m * 2 + jj) * 4 + q) * 1024u + lane * 16u);
-                            acc[m][jj][4 * q] += v.x; acc[m][jj][4 * q + 1] += v.y; acc[m][jj][4 * q + 2] += v.z; acc[m][jj][4 * q + 3] += v.w;
-                        }
-                    }
-                }
-        }
-        char* const o = A.out + (size_t)pos * kPlaneB;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            float bs[16];
-            const float4* bp = reinterpret_cast<const float4*>(smem + kBias2 + (uint32_t)(32 * m + 16 * kg) * 4u);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const float4 v = bp[q]; bs[4 * q] = v.x; bs[4 * q + 1] = v.y; bs[4 * q + 2] = v.z; bs[4 * q + 3] = v.w; }
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                if (jj != ks) continue;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    bf16x8 v;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)elu1(acc[m][jj][8 * hf + e] + bs[8 * hf + e]);
-                    if (ok[jj] && !(A.abl & 2))
-                        *reinterpret_cast<bf16x8*>(o + (uint32_t)(4 * (2 * g + m) + 2 * kg + hf) * kRowB + (uint32_t)(pix[jj] + kS) * 16u) = v;
-                }
-            }
-        }
-    }
-}
+// (r2 A/B record, removed from the source in r6: af_tower_conv2, the same convolution on af_conv_f16s.hip's slab-ring structure —
+//  5.37 ms per tower pass against 4.2: its 32-channel slabs give a wave only 36 MFMAs between barriers)
 
 // ---------------------------------------------------------------------------------------------------------------
 // af_tower_stem: the 5x5 stem (3 -> 128, SAME) + bias + ELU, planes fp32 [B][3][11][11] -> C8 bf16, on the same MFMA.
@@ -1171,12 +915,11 @@ __global__ __launch_bounds__(256) void af_tower_dense_kernel(DenseArgs A) {
 // ------------------------------------------------------------------ host ------------------------------------------------------------------
 struct af_tower {
     int S = 0, width = 0, blocks = 0, device = 0;
-    std::vector<uint4*> w1, w2, v1, v2;     // w: af_tower_conv packing, v: af_tower_conv2 packing
+    std::vector<uint4*> w1, w2;             // A fragments of a block's two convolutions (pack_tower)
     std::vector<float*> b1, b2;
     std::vector<char> set;
     uint4* stem_w = nullptr;
     char* dump = nullptr;
-    char* d_ptrs = nullptr;       // af_tower_persist: [4][blocks] device pointers (w1, w2, b1, b2)
     float* stem_b = nullptr;
     float* heads_w = nullptr;
     float* heads_b = nullptr;
@@ -1221,29 +964,6 @@ static std::vector<uint16_t> pack_tower(const float* w3, const float* w1x1) {
     return out;
 }
 
-// A fragments of af_tower_conv2: [cout pair g][k-half ks][item][cout tile m of the pair][lane][8]; items in the kernel's
-// order: (PROJ: the 4 slabs of the block input, centre tap,) then per 32-channel slab the 9 taps; channel
-// ci = 32*slab + 16*ks + 8*(lane>>5) + e, cout = 64*g + 32*m + perm(lane&31) (same row permutation as pack_tower).
-static std::vector<uint16_t> pack_tower2(const float* w3, const float* w1x1) {
-    const int NSP = w1x1 ? 4 : 0, NIT = NSP + 36;
-    std::vector<uint16_t> out((size_t)2 * 2 * NIT * 2 * 64 * 8);
-    for (int g = 0; g < 2; ++g)
-        for (int ks = 0; ks < 2; ++ks)
-            for (int item = 0; item < NIT; ++item)
-                for (int m_ = 0; m_ < 2; ++m_)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e = 0; e < 8; ++e) {
-                            const int m = lane & 31;
-                            const int co = 64 * g + 32 * m_ + 16 * ((m >> 2) & 1) + 8 * (m >> 4) + 4 * ((m >> 3) & 1) + (m & 3);
-                            const bool proj = item < NSP;
-                            const int slab = proj ? item : (item - NSP) / 9, tap = proj ? 4 : (item - NSP) % 9;
-                            const int ci = 32 * slab + 16 * ks + 8 * (lane >> 5) + e;
-                            const float v = proj ? w1x1[(size_t)co * 128 + ci] : w3[((size_t)co * 128 + ci) * 9 + tap];
-                            out[(((((size_t)(g * 2 + ks) * NIT + item) * 2 + m_) * 64) + lane) * 8 + e] = bf16_rne(v);
-                        }
-    return out;
-}
-
 template <class T>
 static int upload(T** dst, const void* src, size_t bytes) {
     if (*dst) (void)hipFree(*dst);
@@ -1259,8 +979,7 @@ static int g_grid = 0;      // persistent workgroups (0 = one per CU)
 static int g_heads = 1;     // heads' 1x1 convolutions: 1 = af_tower_heads_mfma_kernel (r4), 0 = the VALU kernel (A/B)
 static int g_engine = 3;    // 3 (default, r4): af_tower_conv3 for a block's first convolution + af_tower_conv for its second (bit-identical to 0,
                             //    4.143 vs 4.167 ms per 8192-position tower pass); 0: af_tower_conv for both; 2: af_tower_conv3 for both (its
-                            //    PROJ form is slower: 4.224 ms); 1: af_tower_conv2 (r2 experiment: 5.37 ms — its 32-channel slabs give a
-                            //    wave only 36 MFMAs between barriers; same 3.8 ms floor without staging and stores)
+                            //    PROJ form is slower: 4.224 ms)
 
 extern "C" {
 
@@ -1268,7 +987,7 @@ int af_tower_tune(int32_t key, int32_t value) {
     if (key == 0) { g_depth = value; return AF_TOWER_OK; }
     if (key == 1) { g_grid = value; return AF_TOWER_OK; }
     if (key == 2) { g_abl = value; return AF_TOWER_OK; }
-    if (key == 3) { g_engine = value; return AF_TOWER_OK; }
+    if (key == 3) { if (value != 0 && value != 2 && value != 3) return AF_TOWER_ERR_ARG; g_engine = value; return AF_TOWER_OK; }
     if (key == 4) { g_heads = value; return AF_TOWER_OK; }
     return AF_TOWER_ERR_ARG;
 }
@@ -1288,7 +1007,7 @@ int af_tower_create(int32_t S, int32_t width, int32_t blocks, int32_t device, af
     TW_HIP_OK(hipSetDevice(device));
     af_tower* t = new af_tower();
     t->S = S; t->width = width; t->blocks = blocks; t->device = device;
-    t->w1.assign(blocks, nullptr); t->w2.assign(blocks, nullptr); t->v1.assign(blocks, nullptr); t->v2.assign(blocks, nullptr);
+    t->w1.assign(blocks, nullptr); t->w2.assign(blocks, nullptr);
     t->b1.assign(blocks, nullptr); t->b2.assign(blocks, nullptr);
     t->set.assign(blocks, 0);
 #define TW_ATTR(P, D) TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv<P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
@@ -1296,9 +1015,6 @@ int af_tower_create(int32_t S, int32_t width, int32_t blocks, int32_t device, af
 #undef TW_ATTR
     TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv3<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv3<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_persist<8, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    TW_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_tower_conv2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     { void* q = nullptr; TW_HIP_OK(hipMalloc(&q, 4096)); t->dump = static_cast<char*>(q); }
     *out = t;
     return AF_TOWER_OK;
@@ -1309,13 +1025,10 @@ void af_tower_destroy(af_tower* t) {
     (void)hipSetDevice(t->device);
     for (auto p : t->w1) if (p) (void)hipFree(p);
     for (auto p : t->w2) if (p) (void)hipFree(p);
-    for (auto p : t->v1) if (p) (void)hipFree(p);
-    for (auto p : t->v2) if (p) (void)hipFree(p);
     for (auto p : t->b1) if (p) (void)hipFree(p);
     for (auto p : t->b2) if (p) (void)hipFree(p);
     if (t->stem_w) (void)hipFree(t->stem_w);
     if (t->dump) (void)hipFree(t->dump);
-    if (t->d_ptrs) (void)hipFree(t->d_ptrs);
     if (t->stem_b) (void)hipFree(t->stem_b);
     if (t->heads_w) (void)hipFree(t->heads_w);
     if (t->heads_b) (void)hipFree(t->heads_b);
@@ -1335,12 +1048,8 @@ int af_tower_set_block(af_tower* t, int32_t b, const float* c1_w, const float* c
     TW_HIP_OK(hipSetDevice(t->device));
     const std::vector<uint16_t> p1 = pack_tower(c1_w, nullptr), p2 = pack_tower(c2_w, res_w);
     std::vector<float> bb(128);
-    if (t->d_ptrs) { (void)hipFree(t->d_ptrs); t->d_ptrs = nullptr; }     // (the pointer tables of af_tower_persist are rebuilt at the next forward)
     int rc = upload(&t->w1[b], p1.data(), p1.size() * 2);
     if (!rc) rc = upload(&t->w2[b], p2.data(), p2.size() * 2);
-    const std::vector<uint16_t> q1 = pack_tower2(c1_w, nullptr), q2 = pack_tower2(c2_w, res_w);
-    if (!rc) rc = upload(&t->v1[b], q1.data(), q1.size() * 2);
-    if (!rc) rc = upload(&t->v2[b], q2.data(), q2.size() * 2);
     if (!rc) rc = upload(&t->b1[b], c1_b, 128 * 4);
     for (int i = 0; i < 128; ++i) bb[i] = c2_b[i] + res_b[i];
     if (!rc) rc = upload(&t->b2[b], bb.data(), 128 * 4);
@@ -1482,36 +1191,10 @@ int af_tower_forward(af_tower* t, void* stream, void* x_dev, void* g_dev, int32_
     TW_HIP_OK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (g_grid > 0) ncu = g_grid;
     const int grid = batch < ncu ? batch : ncu;
-    if (g_engine == 4) {         // r4: the whole tower as one launch
-        if (!t->d_ptrs) {        // device copies of the per-block pointer tables (once: the weight buffers are allocated per block)
-            const size_t n = (size_t)t->blocks;
-            std::vector<const void*> tab(4 * n);
-            for (size_t b = 0; b < n; ++b) { tab[b] = t->w1[b]; tab[n + b] = t->w2[b]; tab[2 * n + b] = t->b1[b]; tab[3 * n + b] = t->b2[b]; }
-            int rc = upload(&t->d_ptrs, tab.data(), tab.size() * sizeof(void*));
-            if (rc) return rc;
-        }
-        PersistArgs pa;
-        const void* const* tab = reinterpret_cast<const void* const*>(t->d_ptrs);
-        pa.x = static_cast<char*>(x_dev); pa.g = static_cast<char*>(g_dev);
-        pa.w1 = reinterpret_cast<const uint4* const*>(tab); pa.w2 = reinterpret_cast<const uint4* const*>(tab + t->blocks);
-        pa.b1 = reinterpret_cast<const float* const*>(tab + 2 * t->blocks); pa.b2 = reinterpret_cast<const float* const*>(tab + 3 * t->blocks);
-        pa.blocks = t->blocks; pa.batch = batch; pa.dump = t->dump;
-        hipLaunchKernelGGL((af_tower_persist<8, 6>), dim3(grid), dim3(256), kLds0 + 3 * kPlaneB + kZeroB, st, pa);
-        TW_HIP_OK(hipGetLastError());
-        return AF_TOWER_OK;
-    }
     for (int b = 0; b < t->blocks; ++b) {
         TowerArgs a;
         a.batch = batch; a.abl = g_abl; a.dump = t->dump;
         const char* xin = static_cast<const char*>(x_dev);
-        if (g_engine == 1) {
-            const int gx = batch < ncu / 2 ? batch : ncu / 2;
-            a.in = xin; a.in2 = nullptr; a.w = t->v1[b]; a.bias = t->b1[b]; a.out = static_cast<char*>(g_dev);
-            hipLaunchKernelGGL((af_tower_conv2<false>), dim3(gx, 2), dim3(256), kLds2Total, st, a);
-            a.in = static_cast<const char*>(g_dev); a.in2 = xin; a.w = t->v2[b]; a.bias = t->b2[b]; a.out = static_cast<char*>(x_dev);
-            hipLaunchKernelGGL((af_tower_conv2<true>), dim3(gx, 2), dim3(256), kLds2Total, st, a);
-            continue;
-        }
         a.in = xin; a.in2 = nullptr; a.w = t->w1[b]; a.bias = t->b1[b]; a.out = static_cast<char*>(g_dev);
         // ring depth per kernel: the deepest that hipcc allocates without scratch (a scratch reload's vmcnt(0) would
         // also wait for the LDS-DMA of the next position: measured 400 vs 230 us per launch)

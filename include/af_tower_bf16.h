@@ -68,8 +68,10 @@ int af_tower_dense(af_tower* t, void* stream, const void* vin_dev, const void* p
 
 /* A/B knobs (process-global): key 0 = B-fragment ring depth (0 = per-kernel default, 8, 12, 16), key 1 = persistent
  * workgroups (0 = one per CU), key 2 = profiling ablation bits (results wrong by design: 1 no re-staging, 2 no stores;
- * "no LDS reads" is the build-time macro AF_TOWER_ABL_NOLDS since r3: a run-time test in the MFMA loop was not free), key 3 = convolution kernel (0 af_tower_conv = default, 1 af_tower_conv2: the slab-ring structure of
- * af_conv_f16s.hip with two cout tiles per wave — correct, measured 5 % slower). */
+ * "no LDS reads" is the build-time macro AF_TOWER_ABL_NOLDS since r3: a run-time test in the MFMA loop was not free), key 3 = convolution kernels
+ * (3 = default: af_tower_conv3 — epilogue under the other tile pair's MFMAs — for a block's first convolution and af_tower_conv for its
+ * second; 0 = af_tower_conv for both, bit-identical to 3; 2 = af_tower_conv3 for both), key 4 = the heads' 1x1 convolutions (1 MFMA kernel,
+ * 0 VALU kernel). */
 int af_tower_tune(int32_t key, int32_t value);
 
 int64_t af_tower_flops_per_position(const af_tower* t);   /* 2*MAC of the tower, direct convolution */

@@ -352,8 +352,7 @@ def test_deep_bf16_tower_kernel_matches_fp32_reference(blocks):
     tw.forward(B)
     assert torch.equal(tw.store_nchw(B).float(), out)
     from alphafive_amd import tower_hip              # the other convolution kernels (af_tower_tune key 3) meet the same bar
-    for engine in (0, 1, 2, 4):                      # 0 af_tower_conv for both convolutions, 1 af_tower_conv2, 2 af_tower_conv3 for both,
-                                                     # 4 af_tower_persist: the whole tower as one launch
+    for engine in (0, 2):                            # 0 af_tower_conv for both convolutions, 2 af_tower_conv3 for both
         try:
             tower_hip.tune(3, engine)
             tw.load_nchw(h0)
@@ -363,7 +362,7 @@ def test_deep_bf16_tower_kernel_matches_fp32_reference(blocks):
             tower_hip.tune(3, 3)
         err2 = (out2 - ref).abs()
         assert err2.mean().item() <= 1.1 * err_torch.mean().item() + 1e-4 and err2.max().item() <= 2.0 * err_torch.max().item() + 0.02, engine
-        if engine in (0, 4):                         # the default (conv3 for a block's first convolution) and the single launch change no bit
+        if engine == 0:                              # the default (conv3 for a block's first convolution only) changes no bit against it
             assert torch.equal(out2, out)
         for buf in (tw.x, tw.g):
             assert float(buf[:, :, :S].float().abs().sum()) == 0.0 and float(buf[:, :, S + S * S:].float().abs().sum()) == 0.0

@@ -11,7 +11,7 @@ if os.environ.get("ABL"):
     tower_hip.tune(2, int(os.environ["ABL"]))          # profiling ablations of af_tower_conv (results wrong by design)
 if os.environ.get("ENGINE"):
     from alphafive_amd import tower_hip
-    tower_hip.tune(3, int(os.environ["ENGINE"]))       # 0 af_tower_conv, 1 af_tower_conv2, 2 af_tower_conv3
+    tower_hip.tune(3, int(os.environ["ENGINE"]))       # 0 af_tower_conv, 2 af_tower_conv3, 3 (default) conv3 + conv
 h0 = torch.randn((B, 128, 11, 11), device="cuda").bfloat16()
 net._tower.load_nchw(h0)
 for _ in range(int(os.environ.get("N", 2))): net._tower.forward(B)
