@@ -5,15 +5,16 @@
 // Activations live in zero-padded planes [batch][channel][WP*WP (+pad)], WP = 2*ceil(S/2)+2, so a
 // convolution tap is a constant address shift and no kernel needs bounds checks; every layer writes
 // straight into the next layer's padded layout.  Kernels:
-//   af_conv_wino<LDSU>   (default path, 97 % of the algorithmic FLOPs) Winograd F(2x2,3x3) for every 3x3
+//   af_conv_wino         (97 % of this path's algorithmic FLOPs) Winograd F(2x2,3x3) for every 3x3
 //                        layer with the block's 1x1 projection folded into the Winograd domain; 16
 //                        accumulators in AGPRs, on-the-fly input transform, fused output transform +
-//                        bias + residual + ELU.  3.45 of the 3.86 ms per 4096 leaves.
-//   af_conv_mfma<NT,MT>  direct implicit GEMM (D[cout][pixel] = sum_k W[k][cout] X[k][pixel], k = (cin pair,
-//                        tap)), operands straight from L1/L2 into registers; the pre-Winograd path
-//                        (af_net_tune(0, 0)), kept as the exact-fp32-order reference and for A/B runs.
-//   af_stem_conv, af_value_head, af_policy_head<PPB>   5x5 stem and the two heads (VALU, 0.36 ms together).
-// Measured ladder and the experiments that did not pay are in DESIGN.md §3.2 and profiles/.
+//                        bias + residual + ELU.  3.5 ms per 4096 positions at 11x11 (profiles/r6_02).
+//   af_stem_conv, af_value_head, af_policy_head<PPB>, af_policy_head_mfma   5x5 stem and the two heads.
+// This is the fp32-operand path (af_net_tune(0, 1)): every board size other than 11x11 / 15x15, and the 24-bit
+// leg of bench.py.  The product path on 11x11 / 15x15 is af_conv_f16s.hip (af_net_tune(0, 5), default), which
+// this file's af_net_forward dispatches to.  The variants that lost their A/B (U through LDS, LDS-DMA staging,
+// persistent grid, direct implicit GEMM, sub-batch streams) were removed from the source in r6; their records
+// are in DESIGN_HISTORY.md and profiles/.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,161 +33,9 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4 floats
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float f2a __attribute__((ext_vector_type(2)));               // 8-byte aligned pair (LDS reads)
 
-// LDS-DMA: 16 bytes per lane from global memory straight into LDS at (wave-uniform lds_dst) + lane*16; counted on
-// vmcnt, invisible to hipcc's own wait bookkeeping (callers wait with an explicit s_waitcnt vmcnt before the barrier).
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-struct ConvSeg {
-    const float* in;   // [batch][cin][PP]
-    const float* w;    // packed [cin/2][taps][2][cout_pad]
-    int cin, taps;
-};
-struct ConvArgs {
-    ConvSeg seg[2];
-    int nseg;
-    const float* bias;   // [cout_pad]
-    float* out;          // [batch][cout][PP]
-    int cout, cout_pad, rows, S, HW, WP, PP, elu;
-};
-
 // ELU(alpha=1).  exp(x)-1 through the hardware exp2 (absolute error ~1e-7 at x -> 0-, far inside the
 // 1e-5 parity budget); expm1f costs ~30 VALU ops per element and sat un-overlapped in the epilogue.
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
-
-// One lane's weight fragments for NT cout tiles are NT consecutive floats (cout = col*NT + nt):
-// a single dword / dwordx2 / dwordx4 load.
-template <int NT>
-__device__ __forceinline__ void load_wfrag(const float* __restrict__ p, float (&a)[NT]) {
-    if constexpr (NT == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
-        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-    } else if constexpr (NT == 2) {
-        const float2 v = *reinterpret_cast<const float2*>(p);
-        a[0] = v.x; a[1] = v.y;
-    } else {
-        a[0] = p[0];
-    }
-}
-
-// k loop of one segment, software-pipelined by hand: k-steps are processed in groups of GS
-// (all 9 taps of one cin pair for 3x3, 8 channel pairs for 1x1); the operands of group g+1 are
-// loaded into a second register set before the MFMAs of group g issue, so every load has
-// GS*NT*MT*64 MFMA cycles (4608 for the 128-wide layers, ~2 us) to land.  sched_barrier keeps
-// hipcc from sinking the loads next to their uses (its own schedule prefetched < 1 k-step ahead:
-// 64.7 TFLOP/s; 3-tap groups 79.6; 9-tap groups 88.4 — profiles/r1_02_*).  One wave per SIMD
-// (accumulators in AGPRs, operand sets in VGPRs): the 2-waves/SIMD builds spill under hipcc's
-// 16-register-tuple allocation and measured slower.
-template <int NT, int MT, int TAPS>
-__device__ __forceinline__ void conv_segment(const ConvSeg& sg, const int* __restrict__ base, int kh, int col, int cout_pad,
-                                             int WP, int PP, f32x16 (&acc)[NT][MT]) {
-    constexpr int GS = TAPS == 9 ? 9 : 8;
-    // addressing = wave-uniform 64-bit base (SGPR pair, advanced per group) + one 32-bit per-lane
-    // byte offset (VGPR) + immediate: keeps the load address state at MT+1 VGPRs
-    const char* __restrict__ inb = reinterpret_cast<const char*>(sg.in);
-    const char* __restrict__ wbb = reinterpret_cast<const char*>(sg.w);
-    const uint32_t woff = (uint32_t)(kh * cout_pad + col * NT) * 4u;
-    uint32_t boff[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) boff[mt] = (uint32_t)(base[mt] + kh * PP) * 4u;
-    const int ngroups = (sg.cin / 2) * TAPS / GS;          // even for every layer of this net
-    float a0[GS][NT], b0[GS][MT], a1[GS][NT], b1[GS][MT];
-
-    auto load_group = [&](int g, float (&a)[GS][NT], float (&b)[GS][MT]) {
-        const char* ig;
-        if constexpr (TAPS == 9) ig = inb + (ptrdiff_t)(2 * g) * PP * 4;        // group = all 9 taps of one cin pair
-        else ig = inb + (ptrdiff_t)(2 * g * GS) * PP * 4;                       // group = 8 cin pairs
-        const char* wg = wbb + (size_t)(g * GS) * 2 * cout_pad * 4;             // uniform
-#pragma unroll
-        for (int j = 0; j < GS; ++j) {
-            const ptrdiff_t joff = TAPS == 9 ? (ptrdiff_t)((j / 3 - 1) * WP + (j % 3 - 1)) * 4 : (ptrdiff_t)(2 * j) * PP * 4;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                b[j][mt] = *reinterpret_cast<const float*>(ig + joff + (size_t)boff[mt]);
-            load_wfrag<NT>(reinterpret_cast<const float*>(wg + (size_t)j * 2 * cout_pad * 4 + (size_t)woff), a[j]);
-        }
-    };
-    auto compute = [&](float (&a)[GS][NT], float (&b)[GS][MT]) {
-#pragma unroll
-        for (int j = 0; j < GS; ++j)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][nt], b[j][mt], acc[nt][mt], 0, 0, 0);
-    };
-
-    // (measured r1: an extra "touch" load of the next-but-one cin pair's planes, to give first-touch
-    // L2 misses two phases to land, changed nothing: 5.51 vs 5.50 ms — the remaining s_waitcnt time
-    // is not first-touch latency.)
-    load_group(0, a0, b0);
-    for (int g = 0; g < ngroups; g += 2) {
-        load_group(g + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 2 < ngroups) load_group(g + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int NT, int MT, int MINW>
-__global__ __launch_bounds__(256, MINW) void af_conv_mfma(ConvArgs A) {
-    const int lane = threadIdx.x & 63;
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int col = lane & 31, kh = lane >> 5;
-    const int tile0 = task * MT;
-    if (tile0 * 32 >= A.rows) return;
-    int pos[MT], poff[MT];
-    bool valid[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int row = (tile0 + mt) * 32 + col;
-        valid[mt] = row < A.rows;
-        const int r = valid[mt] ? row : 0;
-        pos[mt] = r / A.HW;
-        const int pix = r - pos[mt] * A.HW;
-        const int y = pix / A.S;
-        poff[mt] = (y + 1) * A.WP + (pix - y * A.S) + 1;
-    }
-    f32x16 acc[NT][MT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
-
-    for (int s = 0; s < A.nseg; ++s) {
-        const ConvSeg sg = A.seg[s];
-        int base[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) base[mt] = pos[mt] * sg.cin * A.PP + poff[mt];
-        if (sg.taps == 9) conv_segment<NT, MT, 9>(sg, base, kh, col, A.cout_pad, A.WP, A.PP, acc);
-        else conv_segment<NT, MT, 1>(sg, base, kh, col, A.cout_pad, A.WP, A.PP, acc);
-    }
-
-    // epilogue: D row = cout, D column = pixel  (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = ((r & 3) + 8 * (r >> 2) + 4 * kh) * NT + nt;   // tile nt, D row i <-> cout i*NT + nt
-            const float bv = A.bias[co];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float v = acc[nt][mt][r] + bv;
-                if (A.elu) v = elu1(v);
-                if (valid[mt] && co < A.cout) A.out[(size_t)(pos[mt] * A.cout + co) * A.PP + poff[mt]] = v;
-            }
-        }
-    }
-}
 
 // ----------------------------------------------------------------------------------------------
 // Winograd F(2x2,3x3) on the matrix cores: Y = A^T [ (G g G^T) (.) (B^T d B) ] A per 2x2 output
@@ -213,16 +62,11 @@ struct WinoArgs {
     const float* bias;   // [cout]
     float* out;          // [batch][cout][PP]
     int cin, cin2, cout, ntiles, T, S, WP, PP;
-    int ntasks;          // workgroup tasks = tile-block groups (padded to 8) x cout tiles
-    int npos;            // LDSU == 2: positions a workgroup's 128 tiles can span (LDS planes per cin)
 };
 
-// LDSU = true: the U stream of the 3x3 segment is shared by the workgroup through LDS (A.u in the
-// slice layout of pack_wino_lds); false: every wave loads its own U fragments (A.u from pack_wino).
-template <int LDSU, int ABL>        // ABL (profiling only): 1 no operand loads in the 3x3 loop, 2 no input transform, 3 no k loops, 4 no epilogue
+// (r1-r3 A/B records, removed from the source in r6: U through LDS — 6 % slower; both operands through LDS by LDS-DMA; a persistent grid;
+//  a direct implicit-GEMM kernel af_conv_mfma — 5.2 ms against 3.5 per 4096 positions: profiles/r6_02_arith_width.json, DESIGN_HISTORY.md)
 __device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
-    __shared__ float4 su[LDSU == 1 ? 3 * 4 * 256 : 1];  // 3 buffers x 4 pair slices x 4 KB (LDSU == 1 only)
-    extern __shared__ __attribute__((aligned(16))) char gsm[];   // LDSU == 2: 3 x (activation planes + U slices)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, kh = lane >> 5;
     const int nct = A.cout >> 5;
@@ -232,13 +76,10 @@ __device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
     const int xcd = bid & 7, rest = bid >> 3;
     const int ct = rest % nct;
     const int tb = ((rest / nct) * 8 + xcd) * 4 + wave;
-    const bool wave_live = tb * 32 < A.ntiles;           // (a dead wave still helps stage U and hits the barriers)
-    if (LDSU == 0 && !wave_live) return;
-    const int grp = (rest / nct) * 8 + xcd;              // tile-block group = 128 consecutive tiles
-    if (LDSU == 2 && grp * 128 >= A.ntiles) return;      // whole workgroup idle (padding of the XCD interleave)
+    if (tb * 32 >= A.ntiles) return;
     const int q = tb * 32 + col;
     const bool valid = q < A.ntiles;
-    const int qq = valid ? q : (LDSU == 2 ? grp * 128 : 0);
+    const int qq = valid ? q : 0;
     const int TT = A.T * A.T;
     const int pos = qq / TT;
     const int t_ = qq - pos * TT;
@@ -259,60 +100,24 @@ __device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
     // k loops: operands ride a 4-deep register ring — the loads of phase p+3 are requested while phase p
     // computes (16 MFMAs = 1024 cycles per phase => >= 3072 cycles to land) — and the wide loads + the
     // transform adds of a phase are spread between its MFMAs by sched_group_barrier.
-    if constexpr (ABL != 3 && ABL != 5 && ABL != 6) {   // ---- 3x3 segment: phase = one cin pair (16 MFMAs) ----  (ABL 3: epilogue only)
+    {   // ---- 3x3 segment: phase = one cin pair (16 MFMAs) ----
         const char* __restrict__ inb = reinterpret_cast<const char*>(A.in);
         const uint32_t boff = (uint32_t)(pos * A.cin * PP + poff0 + kh * PP) * 4u;
         const int npairs = A.cin / 2;                    // multiple of 4
         f4u d0[4] = {}, d1[4] = {}, d2[4] = {}, d3[4] = {};
         auto load_d = [&](int c, f4u (&d)[4]) {
-            if constexpr (ABL == 1) return;
             c = c < npairs ? c : npairs - 1;             // tail: harmless re-load instead of a branch
             const char* ip = inb + (ptrdiff_t)(2 * c) * PP * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)                  // one patch row = 4 consecutive floats (4-byte aligned)
                 d[r] = *reinterpret_cast<const f4u*>(ip + (ptrdiff_t)(r * WP) * 4 + (size_t)boff);
         };
-        auto compute_pair = [&](f4u (&d)[4], float4 (&u)[4]) {
-            float t[16], v[16];
-            if constexpr (ABL == 2) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    M[4 * x + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].x, d[x][0], M[4 * x + 0], 0, 0, 0);
-                    M[4 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].y, d[x][1], M[4 * x + 1], 0, 0, 0);
-                    M[4 * x + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].z, d[x][2], M[4 * x + 2], 0, 0, 0);
-                    M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, d[x][3], M[4 * x + 3], 0, 0, 0);
-                }
-                return;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {                // t = B^T d
-                t[0 + s] = d[0][s] - d[2][s];
-                t[4 + s] = d[1][s] + d[2][s];
-                t[8 + s] = d[2][s] - d[1][s];
-                t[12 + s] = d[1][s] - d[3][s];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                // v = t B
-                v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
-                v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
-                v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
-                v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                M[4 * x + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].x, v[4 * x + 0], M[4 * x + 0], 0, 0, 0);
-                M[4 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].y, v[4 * x + 1], M[4 * x + 1], 0, 0, 0);
-                M[4 * x + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].z, v[4 * x + 2], M[4 * x + 2], 0, 0, 0);
-                M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, v[4 * x + 3], M[4 * x + 3], 0, 0, 0);
-            }
-        };
-        if constexpr (LDSU == 0) {
+        {
             const char* __restrict__ ub = reinterpret_cast<const char*>(A.u);
             const uint32_t woff = wlane * 64u;           // 16 floats per (kh, cout)
             float4 u0[4] = {}, u1[4] = {}, u2[4] = {}, u3[4] = {};
             auto load_u = [&](int c, float4 (&u)[4]) {
-                if constexpr (ABL == 1) return;
-                c = c < npairs ? c : npairs - 1;
+                    c = c < npairs ? c : npairs - 1;
                 const char* up = ub + (size_t)c * 2 * cout * 64;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) u[r] = *reinterpret_cast<const float4*>(up + (size_t)r * 16 + (size_t)woff);
@@ -348,16 +153,10 @@ __device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
             float vA[16], vB[16];
             auto phase = [&](int c_load, f4u (&dl)[4], float4 (&ul)[4], f4u (&dn)[4], float (&vn)[16], float4 (&uc)[4],
                              float (&vc)[16]) {
-                if constexpr (ABL == 0) {
-                    load_d(c_load + 1, dl);    // a patch slot is free one phase earlier than a U slot: 4-phase lead
-                    load_u(c_load, ul);
-                    transform(dn, vn);
-                    mfma16(uc, vc);
-                } else {
-                    load_d(c_load, dl);
-                    load_u(c_load, ul);
-                    compute_pair(dn, uc);      // ablation variants keep the in-phase form (dn == this pair's d there)
-                }
+                load_d(c_load + 1, dl);        // a patch slot is free one phase earlier than a U slot: 4-phase lead
+                load_u(c_load, ul);
+                transform(dn, vn);
+                mfma16(uc, vc);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
@@ -372,204 +171,18 @@ __device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
             load_d(1, d1); load_u(1, u1);
             load_d(2, d2); load_u(2, u2);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABL == 0) {
-                load_d(3, d3);
-                transform(d0, vA);
-                __builtin_amdgcn_sched_barrier(0);
-                for (int c = 0; c < npairs; c += 4) {
-                    phase(c + 3, d0, u3, d1, vB, u0, vA);     // multiply pair c, transform pair c+1, load U c+3 / patch c+4
-                    phase(c + 4, d1, u0, d2, vA, u1, vB);
-                    phase(c + 5, d2, u1, d3, vB, u2, vA);
-                    phase(c + 6, d3, u2, d0, vA, u3, vB);
-                }
-            } else {
-                for (int c = 0; c < npairs; c += 4) {
-                    phase(c + 3, d3, u3, d0, vA, u0, vA);
-                    phase(c + 4, d0, u0, d1, vA, u1, vA);
-                    phase(c + 5, d1, u1, d2, vA, u2, vA);
-                    phase(c + 6, d2, u2, d3, vA, u3, vA);
-                }
-            }
-        } else if constexpr (LDSU == 1) {
-            // U through LDS: a (pair, ct) slice is 4 KB laid out [x][lane][4] (pack_wino_lds), i.e. exactly
-            // one float4 per thread of the workgroup; thread t of wave w stages quad x = w.  Chunks of 4
-            // pairs: chunk k+1 is written to buffer (k+1)%3 at the start of chunk k from registers whose
-            // global loads were issued during chunk k-1 (4096 cycles earlier); one workgroup barrier per
-            // chunk (after phase 1) makes it visible before phase 3 prefetches the next chunk's first pair.
-            const float4* __restrict__ ug = reinterpret_cast<const float4*>(A.u) + (size_t)ct * 256 + threadIdx.x;
-            const size_t ustride = (size_t)nct * 256;    // float4s between consecutive pairs
-            const int nchunks = npairs / 4;
-            auto gload = [&](int c) { c = c < npairs ? c : npairs - 1; return ug[(size_t)c * ustride]; };
-            auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-            float4 G[4], uA[4], uB[4];
-            auto lds_read = [&](int buf, int slot, float4 (&u)[4]) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) u[x] = su[(buf * 4 + slot) * 256 + x * 64 + lane];
-            };
-#pragma unroll
-            for (int p = 0; p < 4; ++p) su[(0 * 4 + p) * 256 + threadIdx.x] = gload(p);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) G[p] = gload(4 + p);
-            load_d(0, d0); load_d(1, d1); load_d(2, d2);
-            lds_barrier();
-            lds_read(0, 0, uA);
+            load_d(3, d3);
+            transform(d0, vA);
             __builtin_amdgcn_sched_barrier(0);
-            auto phase = [&](int c_load, f4u (&dl)[4], float4& g, int g_pair, int rbuf, int rslot, float4 (&un)[4],
-                             f4u (&dc)[4], float4 (&uc)[4]) {
-                load_d(c_load, dl);
-                g = gload(g_pair);
-                lds_read(rbuf, rslot, un);
-                compute_pair(dc, uc);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            int bcur = 0;                                // buffer holding chunk k
-            for (int k = 0; k < nchunks; ++k) {
-                const int bnext = bcur == 2 ? 0 : bcur + 1;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) su[(bnext * 4 + p) * 256 + threadIdx.x] = G[p];   // chunk k+1 -> LDS
-                const int c = 4 * k;
-                phase(c + 3, d3, G[0], c + 8, bcur, 1, uB, d0, uA);
-                phase(c + 4, d0, G[1], c + 9, bcur, 2, uA, d1, uB);
-                lds_barrier();
-                phase(c + 5, d1, G[2], c + 10, bcur, 3, uB, d2, uA);
-                phase(c + 6, d2, G[3], c + 11, bnext, 0, uA, d3, uB);
-                bcur = bnext;
-            }
-        } else {
-            // LDSU == 2 — both operands through LDS, filled by LDS-DMA (global_load_lds_dwordx4, no staging registers):
-            // per chunk of 8 cin the workgroup copies the whole padded planes of the <= npos positions its 128 tiles
-            // touch (full contiguous lines instead of per-lane 4x4 patches: 2.4x fewer bytes and 2.3x fewer, fully
-            // coalesced, requests through the texture-address unit) and the 4 U slices of its cout tile (once per
-            // workgroup instead of once per wave).  3 LDS buffers: chunk i+2 is requested at the one barrier in the
-            // middle of chunk i, when every wave is done with chunk i-1.  Lanes read their patch rows (8-byte aligned
-            // ds_read_b64 pairs) two phases and their U quads (ds_read_b128, lane-linear) one phase ahead of the MFMAs.
-            const int batch = A.ntiles / TT;
-            const int p_lo = (grp * 128) / TT;
-            const uint32_t plane_b = (uint32_t)PP * 4u;
-            const uint32_t abytes = (uint32_t)A.npos * 8u * plane_b;
-            const uint32_t bufb = abytes + 16384u;
-            const uint32_t nunits = abytes >> 4;                 // 16-byte units of activations per chunk
-            const uint32_t upp = plane_b >> 1;                   // units per position (8 planes)
-            const uint32_t lds0 = (uint32_t)(uintptr_t)gsm;      // low 32 bits of a generic LDS pointer = LDS byte address
-            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            uint32_t asrc[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const uint32_t un_ = (uint32_t)j * 256u + threadIdx.x;
-                const uint32_t pi = un_ / upp, off = un_ - pi * upp;
-                int gp = p_lo + (int)pi;
-                gp = gp < batch ? gp : batch - 1;
-                asrc[j] = (uint32_t)gp * (uint32_t)A.cin * plane_b + off * 16u;
-            }
-            const char* __restrict__ usrc = reinterpret_cast<const char*>(A.u) + (size_t)ct * 4096 + threadIdx.x * 16u;
-            const size_t ustride = (size_t)nct * 4096;
-            auto stage = [&](int k, uint32_t bo) {               // chunk k -> the buffer at byte offset bo
-                const uint32_t coff = (uint32_t)k * 8u * plane_b;
-                const uint32_t wdst = lds0 + bo + wv * 1024u;
-#pragma unroll
-                for (int j = 0; j < 9; ++j)
-                    if ((uint32_t)j * 256u + threadIdx.x < nunits)
-                        glds16(inb + (size_t)(asrc[j] + coff), (uint32_t)__builtin_amdgcn_readfirstlane((int)(wdst + (uint32_t)j * 4096u)));
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    glds16(usrc + (size_t)(4 * k + p) * ustride,
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(wdst + abytes + (uint32_t)p * 4096u)));
-            };
-            const uint32_t la = ((uint32_t)(pos - p_lo) * 8u + (uint32_t)kh) * plane_b + (uint32_t)poff0 * 4u;
-            const uint32_t lu = abytes + (uint32_t)lane * 16u;
-            auto rd_d = [&](uint32_t bo, int p, f4u (&d)[4]) {   // patch of pair p of the chunk in buffer bo
-                const char* b = gsm + (bo + la + (uint32_t)(2 * p) * plane_b);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const f2a lo = *reinterpret_cast<const f2a*>(b + r * WP * 4);
-                    const f2a hi = *reinterpret_cast<const f2a*>(b + r * WP * 4 + 8);
-                    d[r][0] = lo[0]; d[r][1] = lo[1]; d[r][2] = hi[0]; d[r][3] = hi[1];
-                }
-            };
-            auto rd_u = [&](uint32_t bo, int p, float4 (&u)[4]) {
-                const char* b = gsm + (bo + lu + (uint32_t)p * 4096u);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) u[x] = *reinterpret_cast<const float4*>(b + x * 1024);
-            };
-            auto transform = [&](f4u (&d)[4], float (&v)[16]) {
-                float t[16];
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) {
-                    t[0 + s_] = d[0][s_] - d[2][s_];
-                    t[4 + s_] = d[1][s_] + d[2][s_];
-                    t[8 + s_] = d[2][s_] - d[1][s_];
-                    t[12 + s_] = d[1][s_] - d[3][s_];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
-                    v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
-                    v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
-                    v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
-                }
-            };
-            auto mfma16 = [&](float4 (&u)[4], float (&v)[16]) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    M[4 * x + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].x, v[4 * x + 0], M[4 * x + 0], 0, 0, 0);
-                    M[4 * x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].y, v[4 * x + 1], M[4 * x + 1], 0, 0, 0);
-                    M[4 * x + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].z, v[4 * x + 2], M[4 * x + 2], 0, 0, 0);
-                    M[4 * x + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[x].w, v[4 * x + 3], M[4 * x + 3], 0, 0, 0);
-                }
-            };
-            f4u dA[4], dB[4];
-            float4 uA[4], uB[4];
-            float vA[16], vB[16];
-            // phase j: multiply pair j, transform pair j+1, read the patch of pair j+2 and the U quads of pair j+1
-            auto phase = [&](uint32_t bo_d, int p_d, f4u (&dl)[4], uint32_t bo_u, int p_u, float4 (&ul)[4], f4u (&dn)[4],
-                             float (&vn)[16], float4 (&uc)[4], float (&vc)[16]) {
-                rd_d(bo_d, p_d, dl);
-                rd_u(bo_u, p_u, ul);
-                transform(dn, vn);
-                mfma16(uc, vc);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            const int nchunks = A.cin / 8;                       // >= 4
-            stage(0, 0u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            stage(1, bufb);
-            rd_d(0u, 0, dA); rd_d(0u, 1, dB); rd_u(0u, 0, uA);
-            transform(dA, vA);
-            __builtin_amdgcn_sched_barrier(0);
-            uint32_t bc = 0u, bn = bufb, bf = 2u * bufb;         // buffers of chunk i, i+1 and the free one
-            for (int i = 0; i < nchunks; ++i) {
-                phase(bc, 2, dA, bc, 1, uB, dB, vB, uA, vA);
-                phase(bc, 3, dB, bc, 2, uA, dA, vA, uB, vB);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk i+1 (requested one chunk ago) has landed
-                __builtin_amdgcn_s_barrier();                       // ... for every wave; all are done with chunk i-1
-                if (i + 2 < nchunks) stage(i + 2, bf);
-                __builtin_amdgcn_sched_barrier(0);
-                phase(bn, 0, dA, bc, 3, uB, dB, vB, uA, vA);
-                phase(bn, 1, dB, bn, 0, uA, dA, vA, uB, vB);
-                const uint32_t t_ = bc; bc = bn; bn = bf; bf = t_;
+            for (int c = 0; c < npairs; c += 4) {
+                phase(c + 3, d0, u3, d1, vB, u0, vA);     // multiply pair c, transform pair c+1, load U c+3 / patch c+4
+                phase(c + 4, d1, u0, d2, vA, u1, vB);
+                phase(c + 5, d2, u1, d3, vB, u2, vA);
+                phase(c + 6, d3, u2, d0, vA, u3, vB);
             }
         }
     }
-    if (!wave_live) return;
-    if (ABL != 3 && ABL != 5 && ABL != 6 && A.in2) {   // ---- 1x1 projection segment: phase = 4 cin pairs (16 MFMAs) ----
+    if (A.in2) {   // ---- 1x1 projection segment: phase = 4 cin pairs (16 MFMAs) ----
         const char* __restrict__ inb = reinterpret_cast<const char*>(A.in2);
         const char* __restrict__ ub = reinterpret_cast<const char*>(A.u2);
         const uint32_t boff = (uint32_t)(pos * A.cin2 * PP + poff0 + kh * PP + WP + 1) * 4u;   // patch centre (1,1)
@@ -622,19 +235,6 @@ __device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
             phase(q + 6, d2, u2, d3, u3);
         }
     }
-    if constexpr (ABL == 4) {          // profiling: no epilogue (keep M alive so the loops are not dead code)
-        float sink = 0.0f;
-#pragma unroll
-        for (int x = 0; x < 16; ++x) sink += M[x][0];
-        if (sink == 12345.678f) A.out[0] = sink;
-        return;
-    }
-    if constexpr (ABL == 6) {          // profiling: the same bytes as the epilogue, as fully coalesced 16-byte stores
-        float4* o4 = reinterpret_cast<float4*>(A.out) + ((size_t)(bid * 4 + wave) * 1024 + lane);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o4[i * 64] = make_float4(bias_r[i], bias_r[i], bias_r[i], bias_r[i]);
-        return;
-    }
     // ---- output transform Y = A^T M A, bias, ELU, store the 2x2 tile ----
     // (bias values were requested before the k loops; each tile row goes out as one 8-byte store, so the
     // lanes of a board row write one contiguous run)
@@ -654,7 +254,7 @@ __device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
         y0[0] = elu1(s0[0] + s0[1] + s0[2] + bv); y0[1] = elu1(s0[1] - s0[2] - s0[3] + bv);
         y1[0] = elu1(s1[0] + s1[1] + s1[2] + bv); y1[1] = elu1(s1[1] - s1[2] - s1[3] + bv);
         float* o = obase + (size_t)co * PP;
-        if (ABL == 5 ? (valid && y0[0] == 12345.678f) : valid) {   // ABL 5 (profiling): no k loops and no stores
+        if (valid) {
             if (ok1x) {
                 *reinterpret_cast<f2u*>(o) = y0;
                 if (ok1y) *reinterpret_cast<f2u*>(o + WP) = y1;
@@ -666,17 +266,7 @@ __device__ __forceinline__ void wino_task(const WinoArgs& A, const int bid) {
     }
 }
 
-// PERSIST: one workgroup per CU walks the task list with stride gridDim.x (a multiple of 8, so a workgroup's
-// tasks stay on its XCD): the stores of task i drain while task i+1 runs instead of holding the CU until the
-// workgroup retires, and there is no per-round dispatch gap.
-template <int LDSU, int ABL = 0, bool PERSIST = false>
-__global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) {
-    if constexpr (PERSIST) {
-        for (int t = blockIdx.x; t < A.ntasks; t += gridDim.x) wino_task<LDSU, ABL>(A, t);
-    } else {
-        wino_task<LDSU, ABL>(A, blockIdx.x);
-    }
-}
+__global__ __launch_bounds__(256, 1) void af_conv_wino(WinoArgs A) { wino_task(A, (int)blockIdx.x); }
 
 // (r1 experiment, removed: af_conv_wino2 split the 16 Winograd-domain accumulators over a wave pair —
 // 128 AGPRs per wave, two waves per SIMD, partial outputs swapped through LDS.  Correct, but hipcc spilled
@@ -1011,12 +601,9 @@ struct af_net {
     std::vector<void*> allocs;
     // device weights
     float *stem_w, *stem_b;
-    float *conv1_w[5], *conv1_b[5], *conv2_w[5], *res_w[5], *sum_b[5];
-    float *wino1_u[5], *wino2_u[5], *winor_u[5], *wino1_ul[5], *wino2_ul[5];
+    float *conv1_b[5], *sum_b[5];
+    float *wino1_u[5], *wino2_u[5], *winor_u[5];
     int T;
-    std::vector<hipStream_t> streams;
-    std::vector<hipEvent_t> events;
-    hipEvent_t ev_start = nullptr;
     hipStream_t branch_stream = nullptr;
     hipEvent_t ev_trunk = nullptr, ev_value = nullptr;
     float *vc_w, *vc_b, *v1_w, *v1_b, *v2_w, *v2_b, *pc_w, *pc_b, *pf_w, *pf_b;
@@ -1043,16 +630,6 @@ static int net_upload(af_net* n, float** p, const std::vector<float>& h) {
     return AF_NET_OK;
 }
 
-// HWIO [taps][cin][cout] -> k-pair-major stream [cin/2][taps][2][cout_pad]
-static std::vector<float> pack_conv(const std::vector<float>& w, int taps, int cin, int cout) {
-    const int cp = pad32(cout);
-    std::vector<float> out((size_t)cin * taps * cp, 0.0f);
-    for (int c = 0; c < cin; ++c)
-        for (int t = 0; t < taps; ++t)
-            for (int co = 0; co < cout; ++co)
-                out[((((size_t)(c / 2) * taps + t) * 2) + (c & 1)) * cp + co] = w[((size_t)t * cin + c) * cout + co];
-    return out;
-}
 // Winograd weights U = G g G^T per (cin, cout), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], packed
 // [cin/2][2][cout][npos] (one lane's npos values contiguous).  taps == 9: all 16 (xi,nu); taps == 1: the centre-tap kernel of a 1x1
 // projection, whose only non-zero positions are (1,1),(1,2),(2,1),(2,2).
@@ -1078,20 +655,6 @@ static std::vector<float> pack_wino(const std::vector<float>& w, int taps, int c
                 out[((((size_t)(c / 2) * 2) + (c & 1)) * cout + co) * npos + p] = (float)u;
             }
         }
-    return out;
-}
-// U for the LDS path: a (pair c, cout tile ct) slice = 1024 floats [x][lane = kh*32+col][e],
-// (xi,nu) = 4x+e, cin = 2c+kh, cout = ct*32+col; slices ordered [c][ct].
-static std::vector<float> pack_wino_lds(const std::vector<float>& w, int cin, int cout) {
-    const std::vector<float> u = pack_wino(w, 9, cin, cout);        // [c/2][2][cout][16]
-    const int nct = cout / 32;
-    std::vector<float> out(u.size());
-    for (int c = 0; c < cin / 2; ++c)
-        for (int kh = 0; kh < 2; ++kh)
-            for (int co = 0; co < cout; ++co)
-                for (int p = 0; p < 16; ++p)
-                    out[(((size_t)c * nct + co / 32) * 4 + p / 4) * 256 + (kh * 32 + co % 32) * 4 + p % 4] =
-                        u[(((size_t)c * 2 + kh) * cout + co) * 16 + p];
     return out;
 }
 static std::vector<float> pad_bias(const std::vector<float>& a, const std::vector<float>* b, int cout) {
@@ -1146,10 +709,7 @@ void af_net_destroy(af_net* n) {
     (void)hipSetDevice(n->device);
     for (void* p : n->allocs) (void)hipFree(p);
     f16s_destroy(n->f16s);
-    for (hipStream_t s_ : n->streams) (void)hipStreamDestroy(s_);
-    for (hipEvent_t e_ : n->events) (void)hipEventDestroy(e_);
     if (n->branch_stream) (void)hipStreamDestroy(n->branch_stream);
-    if (n->ev_start) (void)hipEventDestroy(n->ev_start);
     if (n->ev_trunk) (void)hipEventDestroy(n->ev_trunk);
     if (n->ev_value) (void)hipEventDestroy(n->ev_value);
     delete n;
@@ -1180,15 +740,10 @@ int af_net_finalize(af_net* n) {
     for (int i = 0; i < 5; ++i) {
         const Block& b = kBlocks[i];
         const std::string s = b.name;
-        UP(conv1_w[i], pack_conv(V[s + "_conv1/kernel"], 9, b.cin, b.cout));
         UP(conv1_b[i], pad_bias(V[s + "_conv1/bias"], nullptr, b.cout));
-        UP(conv2_w[i], pack_conv(V[s + "_conv2/kernel"], 9, b.cout, b.cout));
-        UP(res_w[i], pack_conv(V[s + "_res/kernel"], 1, b.cin, b.cout));
         UP(sum_b[i], pad_bias(V[s + "_conv2/bias"], &V[s + "_res/bias"], b.cout));
         UP(wino1_u[i], pack_wino(V[s + "_conv1/kernel"], 9, b.cin, b.cout));
         UP(wino2_u[i], pack_wino(V[s + "_conv2/kernel"], 9, b.cout, b.cout));
-        UP(wino1_ul[i], pack_wino_lds(V[s + "_conv1/kernel"], b.cin, b.cout));
-        UP(wino2_ul[i], pack_wino_lds(V[s + "_conv2/kernel"], b.cout, b.cout));
         UP(winor_u[i], pack_wino(V[s + "_res/kernel"], 1, b.cin, b.cout));
     }
     UP(vc_w, V["value/conv/kernel"]); UP(vc_b, V["value/conv/bias"]); UP(v1_w, V["value/fc1/kernel"]);
@@ -1205,8 +760,6 @@ int af_net_finalize(af_net* n) {
     if (rc) return rc;
     NET_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_policy_head_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-    NET_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(af_conv_wino<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
     if (!n->branch_stream) {
         NET_HIP_OK(hipStreamCreateWithFlags(&n->branch_stream, hipStreamNonBlocking));
         NET_HIP_OK(hipEventCreateWithFlags(&n->ev_trunk, hipEventDisableTiming));
@@ -1218,70 +771,24 @@ int af_net_finalize(af_net* n) {
 
 }  // extern "C"
 
-static int g_abl = 0;    // profiling: ablation variant of af_conv_wino<false>
-static int g_pgrid = 256; // workgroups of the persistent variant (g_wino == 4)
 static int g_f16s_abl = 0;
-static int g_wino = 5;   // 5: fp16 split-operand implicit GEMM on 11x11 boards (default; other sizes fall through to 1); 1: af_conv_wino<false>; 2: af_conv_wino<true> (U through LDS: measured 6 % slower); 0: direct af_conv_mfma
+static int g_wino = 5;   // 5: fp16 split-operand implicit GEMM on 11x11 / 15x15 boards (default; other sizes run 1); 1: af_conv_wino (fp32 MFMA, Winograd)
 
-static void launch_wino(hipStream_t st, const af_net* n, int batch, const float* in, const float* u, const float* ul, int cin,
+static void launch_wino(hipStream_t st, const af_net* n, int batch, const float* in, const float* u, int cin,
                         const float* in2, const float* u2, int cin2, const float* bias, float* out, int cout) {
     WinoArgs a;
-    a.in = in; a.u = g_wino == 2 ? ul : u; a.in2 = in2; a.u2 = u2; a.bias = bias; a.out = out;
+    a.in = in; a.u = u; a.in2 = in2; a.u2 = u2; a.bias = bias; a.out = out;
     a.cin = cin; a.cin2 = cin2; a.cout = cout; a.T = n->T; a.S = n->S; a.WP = n->WP; a.PP = n->PP;
     a.ntiles = batch * n->T * n->T;
     const int ntb = (a.ntiles + 31) / 32;
     const int ngrp8 = (((ntb + 3) / 4) + 7) / 8 * 8;      // tile-block groups, padded to the 8-XCD interleave
-    // LDS-DMA path: needs the staging loop's 9 rounds and 3 buffers of (npos x 8 planes + 16 KB of U) to fit
-    a.npos = 127 / (n->T * n->T) + 2;
-    const size_t gl_bytes = 3 * ((size_t)a.npos * 8 * n->PP * 4 + 16384);
-    const bool gl_ok = (size_t)a.npos * 8 * n->PP * 4 / 16 <= 9 * 256 && gl_bytes <= 160 * 1024 && cin % 8 == 0 && cin >= 32;
-    if (g_wino == 3 && gl_ok && g_abl == 0) {
-        a.u = ul;
-        hipLaunchKernelGGL((af_conv_wino<2, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), gl_bytes, st, a);
-        return;
-    }
-    a.ntasks = ngrp8 * (cout / 32);
-    if (g_wino == 4 && g_abl == 0) {
-        hipLaunchKernelGGL((af_conv_wino<0, 0, true>), dim3(a.ntasks < g_pgrid ? a.ntasks : g_pgrid), dim3(256), 0, st, a);
-        return;
-    }
-    if (g_wino == 2) hipLaunchKernelGGL((af_conv_wino<1, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 1) hipLaunchKernelGGL((af_conv_wino<0, 1>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 4) hipLaunchKernelGGL((af_conv_wino<0, 4>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 3) hipLaunchKernelGGL((af_conv_wino<0, 3>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 6) hipLaunchKernelGGL((af_conv_wino<0, 6>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 5) hipLaunchKernelGGL((af_conv_wino<0, 5>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else if (g_abl == 2) hipLaunchKernelGGL((af_conv_wino<0, 2>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((af_conv_wino<0, 0>), dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(af_conv_wino, dim3(ngrp8 * (cout / 32)), dim3(256), 0, st, a);
 }
 
-template <int NT, int MT, int MINW>
-static void launch_shape(hipStream_t st, const ConvArgs& a) {
-    const int tiles = (a.rows + 31) / 32;
-    const int tasks = (tiles + MT - 1) / MT;
-    hipLaunchKernelGGL((af_conv_mfma<NT, MT, MINW>), dim3((tasks + 3) / 4), dim3(256), 0, st, a);
-}
-
-static void launch_conv(hipStream_t st, const ConvArgs& a) {
-    if (a.cout_pad == 128) {
-        launch_shape<4, 2, 1>(st, a);      // r1: <4,1> at 2-3 waves/SIMD measured 5 % slower
-    } else if (a.cout_pad == 64) {
-        launch_shape<2, 4, 1>(st, a);
-    } else {
-        launch_shape<1, 4, 1>(st, a);
-    }
-}
-
-extern "C" {
-
-}  // extern "C"
 
 static int g_phead = 1;          // 1: af_policy_head_mfma for boards up to 11x11; 0: VALU head
 static int g_branch = 1;         // 1: value branch on a side stream
-static int g_substreams = 1;     // >1: split the batch into that many sub-batches, one HIP stream each
-static int g_subbatch = 0;       // 0: batch / g_substreams
 static int g_fhead = 1;          // 1: split-operand path computes the heads itself (fused 1x1 conv + MFMA dense layers); 0: af_value_head / af_policy_head_mfma
-static int g_seqsub = 1;         // >1: that many sequential sub-batches on the caller's stream (Infinity-Cache residency experiment)
 
 // forward pass of positions [b0, b0+batch) on stream st
 static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int b0, int batch, float* policy_all, float* value_all) {
@@ -1294,7 +801,7 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
     float* g[5];
     float* o[5];
     for (int i = 0; i < 5; ++i) { g[i] = n->g[i] + po * kBlocks[i].cout; o[i] = n->o[i] + po * kBlocks[i].cout; }
-    const bool split16 = g_wino == 5 && n->f16s != nullptr;
+    const bool split16 = g_wino == 5 && n->f16s != nullptr;     // (board sizes without the split-operand path run the fp32 Winograd path)
     const bool fhead = split16 && g_fhead;                 // heads fused into the split-operand path
     if (split16) {
         f16s_set_ablation(n->f16s, g_f16s_abl);
@@ -1334,24 +841,10 @@ static int forward_range(af_net* n, hipStream_t st, const float* planes_all, int
         if (split16) {
             if (i == 2 && f16s_value_branch(n->f16s, st, batch, o[2], WP, PP, fhead ? value : nullptr)) return AF_NET_ERR_HIP;
             if (i == 4 && f16s_policy_branch(n->f16s, st, batch, o[4], WP, PP, fhead ? policy : nullptr)) return AF_NET_ERR_HIP;
-        } else if (g_wino) {
-            // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
-            launch_wino(st, n, batch, block_in[i], n->wino1_u[i], n->wino1_ul[i], b.cin, nullptr, nullptr, 0,
-                        n->conv1_b[i], g[i], b.cout);
-            launch_wino(st, n, batch, g[i], n->wino2_u[i], n->wino2_ul[i], b.cout, block_in[i], n->winor_u[i], b.cin,
-                        n->sum_b[i], o[i], b.cout);
         } else {
-            ConvArgs a;
-            memset(&a, 0, sizeof(a));
-            a.rows = batch * HW; a.S = S; a.HW = HW; a.WP = WP; a.PP = PP; a.elu = 1;
-            a.cout = b.cout; a.cout_pad = pad32(b.cout);
-            a.nseg = 1; a.seg[0] = ConvSeg{block_in[i], n->conv1_w[i], b.cin, 9};
-            a.bias = n->conv1_b[i]; a.out = g[i];
-            launch_conv(st, a);
-            a.nseg = 2; a.seg[0] = ConvSeg{g[i], n->conv2_w[i], b.cout, 9};
-            a.seg[1] = ConvSeg{block_in[i], n->res_w[i], b.cin, 1};
-            a.bias = n->sum_b[i]; a.out = o[i];
-            launch_conv(st, a);
+            // conv1 3x3 + ELU (network.py:54); conv2 3x3 (+) 1x1 projection, add, ELU (network.py:53,55,56)
+            launch_wino(st, n, batch, block_in[i], n->wino1_u[i], b.cin, nullptr, nullptr, 0, n->conv1_b[i], g[i], b.cout);
+            launch_wino(st, n, batch, g[i], n->wino2_u[i], b.cout, block_in[i], n->winor_u[i], b.cin, n->sum_b[i], o[i], b.cout);
         }
         if (i == 2) {
             if (!fhead)
@@ -1386,61 +879,17 @@ extern "C" {
 int af_net_forward(af_net* n, void* stream, const float* planes, int32_t batch, float* policy, float* value) {
     if (!n || !planes || !policy || !value || batch < 1 || batch > n->max_batch) return AF_NET_ERR_ARG;
     if (!n->ready) return AF_NET_ERR_STATE;
-    hipStream_t st = (hipStream_t)stream;
-    // concurrent sub-batches only on the fp32 paths (their buffers are offset by b0): the split-operand path keeps ONE set
-    // of activation buffers indexed from position 0, so chains running side by side would overwrite each other
-    const int ns = (g_wino == 5 && n->f16s != nullptr) ? 1 : g_substreams;
-    if (g_seqsub > 1 && batch >= 512 * g_seqsub) {
-        // sequential sub-batches on ONE stream: the split-operand path re-uses its activation buffers for every sub-batch
-        // (positions are indexed from 0), so a sub-batch's producer -> consumer traffic can stay inside the Infinity Cache
-        const int sub = ((batch + g_seqsub - 1) / g_seqsub + 255) / 256 * 256;
-        for (int b0 = 0; b0 < batch; b0 += sub) {
-            const int rc = forward_range(n, st, planes, b0, batch - b0 < sub ? batch - b0 : sub, policy, value);
-            if (rc) return rc;
-        }
-        return AF_NET_OK;
-    }
-    if (ns <= 1 || batch < 64 * ns) return forward_range(n, st, planes, 0, batch, policy, value);
-    // sub-batches in flight on side streams: each chain's activations (<= 266 KB/position between two
-    // layers) stay inside the 256 MB Infinity Cache, and one chain's kernel tails overlap another's bodies
-    if ((int)n->streams.size() < ns) {
-        while ((int)n->streams.size() < ns) {
-            hipStream_t side_stream;
-            hipEvent_t side_event;
-            NET_HIP_OK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-            NET_HIP_OK(hipEventCreateWithFlags(&side_event, hipEventDisableTiming));
-            n->streams.push_back(side_stream);
-            n->events.push_back(side_event);
-        }
-        NET_HIP_OK(hipEventCreateWithFlags(&n->ev_start, hipEventDisableTiming));
-    }
-    NET_HIP_OK(hipEventRecord(n->ev_start, st));
-    const int sub = g_subbatch > 0 ? g_subbatch : ((batch + ns - 1) / ns + 31) / 32 * 32;
-    for (int i = 0; i < ns; ++i) NET_HIP_OK(hipStreamWaitEvent(n->streams[i], n->ev_start, 0));
-    int k = 0;
-    for (int b0 = 0; b0 < batch; b0 += sub, ++k) {
-        const int nb = batch - b0 < sub ? batch - b0 : sub;
-        const int rc = forward_range(n, n->streams[k % ns], planes, b0, nb, policy, value);
-        if (rc) return rc;
-    }
-    for (int i = 0; i < ns; ++i) {
-        NET_HIP_OK(hipEventRecord(n->events[i], n->streams[i]));
-        NET_HIP_OK(hipStreamWaitEvent(st, n->events[i], 0));
-    }
-    return AF_NET_OK;
+    // (r1-r5 A/B records, removed from the source in r6: concurrent sub-batches on side streams and sequential sub-batches that keep a
+    //  layer's output inside the Infinity Cache — 1.415 / 1.621 ms per 4096 positions as 2 / 4 sub-batches against 1.330: profiles/r5_41)
+    return forward_range(n, (hipStream_t)stream, planes, 0, batch, policy, value);
 }
 
-int af_net_tune(int32_t cout_pad, int32_t shape) {
-    if (cout_pad == 0) { g_wino = shape; return AF_NET_OK; }     // 0: conv path (2 Winograd+LDS, 1 Winograd, 0 direct)
-    if (cout_pad == 6) { g_pgrid = shape; return AF_NET_OK; }                       // 6: persistent-grid size
-    if (cout_pad == 5) { g_phead = shape; return AF_NET_OK; }                       // 5: MFMA policy head (1/0)
-    if (cout_pad == 4) { g_branch = shape; return AF_NET_OK; }                      // 4: value branch on a side stream (1/0)
-    if (cout_pad == 3) { g_abl = shape; return AF_NET_OK; }                         // 3: ablation variant (profiling)
-    if (cout_pad == 8) { g_seqsub = shape < 1 ? 1 : shape; return AF_NET_OK; }
-    if (cout_pad == 9) { g_fhead = shape ? 1 : 0; return AF_NET_OK; }                 // 9: heads on the split-operand path (1/0)        // 8: sequential sub-batches
-    if (cout_pad == 7) { g_f16s_abl = shape; return AF_NET_OK; }                      // 7: ablation bits of af_conv_f16s (profiling)
-    if (cout_pad == 1) { g_substreams = shape < 1 ? 1 : shape; return AF_NET_OK; }   // 1: number of sub-batch streams
-    if (cout_pad == 2) { g_subbatch = shape; return AF_NET_OK; }                     // 2: sub-batch size (0 = batch/streams)
+int af_net_tune(int32_t key, int32_t value) {
+    if (key == 0) { if (value != 1 && value != 5) return AF_NET_ERR_ARG; g_wino = value; return AF_NET_OK; }   // 0: conv path (5 split fp16, 1 fp32 Winograd)
+    if (key == 5) { g_phead = value; return AF_NET_OK; }                            // 5: MFMA policy head of the fp32 path (1/0)
+    if (key == 4) { g_branch = value; return AF_NET_OK; }                           // 4: value branch on a side stream (fp32 path: 1/0; 2 forces it on path 5)
+    if (key == 9) { g_fhead = value ? 1 : 0; return AF_NET_OK; }                    // 9: heads on the split-operand path (1/0)
+    if (key == 7) { g_f16s_abl = value; return AF_NET_OK; }                         // 7: A/B and profiling bits of af_conv_f16s.hip
     return AF_NET_ERR_ARG;
 }
 

@@ -178,9 +178,6 @@ def roofline_info(board_size=11):
                           "(whole forward timed; the convolution kernels carry 99 % of the algorithmic FLOPs, each MAC issued as 3 fp16 MFMA MACs)",
                 "peak_tflops": 2500.0, "issued_flop_per_position": 2 * 3 * _SPLIT_MAC_PER_PIXEL * 121,
                 "algorithmic_bytes_per_position": _SPLIT_BYTES_PER_POSITION}
-    if _conv_mode == 0:
-        return {"backend": "hip (af_net.hip: fp32 MFMA direct implicit-GEMM convs, fused bias/ELU/residual)", "peak_tflops": 157.3,
-                "kernel": "af_net_forward = af_stem_conv + 10x af_conv_mfma + head kernels (whole forward timed; fp32 operands, v_mfma_f32_32x32x2_f32)"}
     return {"backend": "hip (af_net.hip: fp32 MFMA Winograd F(2x2,3x3) convs, fused transforms/bias/ELU/residual)",
             "kernel": "af_net_forward = af_stem_conv + 10x af_conv_wino + af_value_head + af_policy_head "
                       "(whole forward timed; af_conv_wino carries 97 % of the algorithmic FLOPs; achieved = "
@@ -189,9 +186,9 @@ def roofline_info(board_size=11):
 
 
 def tune(key, value):
-    """Benchmark knob (af_net_tune, include/af_net.h): key 0 = conv path (5 fp16 split-operand implicit GEMM = default
-    on 11x11, 1 fp32 Winograd, 2 Winograd + LDS-shared U, 3 / 4 Winograd variants, 0 fp32 direct); key 1/2 = sub-batch
-    streams/size; key 3 / 7 = ablation variants (profiling only)."""
+    """Benchmark / A-B knob (af_net_tune, include/af_net.h): key 0 = conv path (5 fp16 split-operand implicit GEMM = default on
+    11x11 / 15x15, 1 fp32 MFMA Winograd); key 7 = A/B and profiling bits of the split-operand path; key 9 = fused heads (1) or the
+    fp32 head kernels (0); key 4 / 5 = side stream / MFMA policy head of the fp32 path.  Unknown keys and values raise NetError."""
     global _conv_mode
     lib().af_net_tune.argtypes = [C.c_int32, C.c_int32]
     _check(lib().af_net_tune(key, value), "af_net_tune")

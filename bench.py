@@ -322,7 +322,7 @@ def live_pmc(G, ticks=400, last=200, timeout_s=180, probe="probe_tick_min.py", e
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-FP32_LEG_MODE = 1      # fastest fp32-MFMA path at 4096 positions: Winograd register ring, 3.48 ms vs 1.42 (tools/probe_arith_width.py, profiles/r6_02)
+FP32_LEG_MODE = 1      # the fp32-MFMA path (Winograd register ring): 3.48 ms per 4096 positions vs 1.42 (tools/probe_arith_width.py, profiles/r6_02)
 
 EXTRA_LEGS = {
     # BASELINE.json configs[3]: 15x15, 800 sims/move (cap 942 = the reference's 642 - 500 head-room), 4096 games
@@ -490,10 +490,10 @@ def main():
                          "the default run measures it in a leg of its own (config2_memo_*)")
     ap.add_argument("--pipe-values", action="store_true",
                     help="W / Q in fp64: the arithmetic of main.py's pipe-fed workers (networkAPI.py:72); default = the pv_fn path")
-    ap.add_argument("--conv-mode", type=int, default=5, choices=[0, 1, 2, 3, 4, 5],
+    ap.add_argument("--conv-mode", type=int, default=5, choices=[1, 5],
                     help="af_net_tune(0, .): 5 (default) = fp16 split-operand implicit GEMM (22 mantissa bits, 3 fp16 MFMA products per "
-                         "MAC); 0..4 = the fp32-MFMA paths of af_net.hip (24 bits, the reference's width): 0 direct, 1-4 Winograd F(2x2,3x3) "
-                         "variants.  The default run measures mode %d in a leg of its own (config2_fp32mfma_*)" % FP32_LEG_MODE)
+                         "MAC); 1 = the fp32-MFMA Winograd path of af_net.hip (24 bits, the reference's width).  The default run measures "
+                         "mode 1 in a leg of its own (config2_fp32mfma_*)")
     ap.add_argument("--net", default="hip", choices=["hip", "torch", "deep-bf16", "deep-bf16-torch"],
                     help="hip (default): the hand-written kernels, fails without libaf_net.so; torch: PyTorch-ROCm ops "
                          "(reference only); deep-bf16 = BASELINE configs[4]: 8-block width-128 net in bf16 (use with --games 8192)")

@@ -42,23 +42,22 @@ int af_net_finalize(af_net* n);
  * Asynchronous on `stream` (hipStream_t; NULL = default stream). */
 int af_net_forward(af_net* n, void* stream, const float* planes_dev, int32_t batch, float* policy_dev, float* value_dev);
 
-/* Benchmark / A-B knobs (process-global):
- *   key 0: conv path — 5 fp16 split-operand implicit GEMM (af_conv_f16s.hip; 11x11 boards), 1 fp32 Winograd register
- *          ring, 2 Winograd with U shared through LDS, 3 Winograd with both operands staged by LDS-DMA, 4 Winograd on a
- *          persistent grid, 0 fp32 direct implicit GEMM
- *   key 1: number of sub-batch side streams (default 1)      key 2: sub-batch size (0 = batch / streams)
- *   key 3: ablation variant of the Winograd kernel (profiling only; results are wrong by design)
- *   key 4: value branch on a side stream (default 1: on the fp32 paths only; since r5 path 5 runs both branches on one stream —
- *          2 forces the side stream there too, for A/B)           key 5: MFMA policy head (default 1)
- *   key 6: workgroups of the persistent variant (default 256)
- *   key 7: bits of path 5 — 1 / 2 / 4 profiling ablations (results wrong by design), 16 VALU stem, 32 one workgroup per CU in the
- *          32-channel-input layers; r5 launch structures, each bit selecting the launch it replaced (same results bit for bit):
+/* Benchmark / A-B knobs (process-global; an unknown key or value returns AF_NET_ERR_ARG):
+ *   key 0: conv path — 5 (default) fp16 split-operand implicit GEMM (af_conv_f16s.hip; 11x11 and 15x15 boards: three fp16 MFMA products
+ *          per MAC, fp32 accumulate, 22 operand mantissa bits), 1 fp32 MFMA Winograd F(2x2,3x3) (af_net.hip: 24 bits — the path of every
+ *          other board size, and bench.py's config2_fp32mfma leg)
+ *   key 4: value branch on a side stream (default 1: on the fp32 path only; 2 forces it on path 5 too, for A/B)
+ *   key 5: MFMA policy head of the fp32 path (default 1)
+ *   key 7: bits of path 5 — 1 / 2 / 4 / 8 / 4096 profiling ablations (results wrong by design: no slab loads after the first position /
+ *          no stores / loads from a hot address / stores, loads addressed modulo 128 positions), 16 VALU stem, 32 one workgroup per CU in
+ *          the 32-channel-input layers; launch structures, each bit selecting the launch it replaced (same results bit for bit):
  *          64 two-halves launch on 15x15 (instead of the 4-tile / 3-tile classes + corner kernel), 128 one workgroup per position at
  *          batches <= 8 (instead of the pixel-tile split), 256 two launches per 32-wide block (instead of af_block_f16s),
- *          512 / 1024 the two-branch launch order at batches <= 8 / above (instead of the value branch as a workgroup class)
- *   key 8: sequential sub-batches on one stream (default 1 = none; measured slower)
+ *          512 / 1024 the two-branch launch order at batches <= 8 / above (instead of the value branch as a workgroup class),
+ *          2048 (r6) nine dependent launches at batches <= 8 (instead of the single launch of dataflow roles)
  *   key 9: path 5 computes the heads itself — 1x1 head convolutions fused into the last conv of each branch, dense layers on
- *          the same split-operand MFMA (default 1); 0 = the fp32 head kernels of the other paths on fp32 planes */
+ *          the same split-operand MFMA (default 1); 0 = the fp32 head kernels of path 1 on fp32 planes
+ * (removed in r6 with the kernels they selected: conv paths 0 / 2 / 3 / 4, keys 1 / 2 / 3 / 6 / 8) */
 int af_net_tune(int32_t key, int32_t value);
 
 /* Tests / debugging of the fp16 split-operand path (conv path 5, 11x11 boards): intermediate activation `which`

@@ -92,8 +92,8 @@ def test_flop_count_matches_survey():
 
 
 def test_alternate_conv_paths_agree_with_fp64():
-    """The fp32 paths behind af_net_tune(0, .) — direct implicit GEMM (0), Winograd register ring (1), LDS-shared U (2),
-    LDS-DMA (3), persistent grid (4) — and the default fp16 split-operand path (5) all stay within the bar."""
+    """The fp32-MFMA Winograd path (af_net_tune(0, 1): 24-bit operands, the path of the other board sizes and of bench.py's
+    config2_fp32mfma leg) and the default fp16 split-operand path (5) both stay within the bar; removed paths are refused."""
     import torch
     from alphafive_amd import net_hip
     from alphafive_amd.network import ResNet
@@ -104,11 +104,14 @@ def test_alternate_conv_paths_agree_with_fp64():
     xt = torch.from_numpy(x).cuda()
     p64, v64 = net_fp64.forward(net.variables, x[:32])
     try:
-        for mode in (0, 2, 3, 4, 1, 5):
+        for mode in (1, 5):
             net_hip.tune(0, mode)
             p, v = pv(xt)
             assert np.abs(v[:32].cpu().numpy() - v64).max() < 1e-5, mode
             assert np.abs(p[:32].cpu().numpy() - p64).max() < 1e-5, mode
+        for gone in (0, 2, 3, 4):
+            with pytest.raises(net_hip.NetError):
+                net_hip.tune(0, gone)
         # ... and the split-operand path with the r1 head kernels on fp32 planes instead of its own fused heads (af_net_tune(9, 0)),
         # plus slot independence of the default path: a position's outputs do not depend on where in the batch it sits
         net_hip.tune(9, 0)

@@ -1,5 +1,5 @@
 """Arithmetic width next to speed: the forward at 4096 positions on every convolution path of af_net_tune(0, .)
-— 5 = the default fp16 split-operand path (22 mantissa bits), 0..4 = fp32 MFMA paths (24 bits) — timed with HIP events, and its
+— 5 = the default fp16 split-operand path (22 mantissa bits), 1 = the fp32 MFMA Winograd path (24 bits; r6_02 also has the removed 0 / 2 / 3 / 4) — timed with HIP events, and its
 worst |dv| / |dp| against (a) the fp64 restatement on 512 positions and (b) ResNet.eval_torch (PyTorch-ROCm fp32 ops) on all of them."""
 import json
 import os
@@ -26,7 +26,7 @@ p64, v64 = net_fp64.forward(net.variables, x[:512])
 pt, vt = net.eval_torch(xt)
 out = {"B": B, "torch_fp32_vs_fp64": {"dv": float(np.abs(vt[:512].cpu().numpy() - v64).max()), "dp": float(np.abs(pt[:512].cpu().numpy() - p64).max())}}
 try:
-    for mode in (5, 0, 1, 2, 3, 4):
+    for mode in (5, 1):
         net_hip.tune(0, mode)
         for _ in range(3):
             p, v = pv(xt)
