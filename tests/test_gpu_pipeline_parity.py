@@ -84,10 +84,10 @@ def _drain_into(sp, got, cap=256):
             return
 
 
-def _run_pipeline(cfg, G, net, sample, memo, n=16, max_replays=40000):
+def _run_pipeline(cfg, G, net, sample, memo, n=16, max_replays=40000, value_f64=False):
     """The bench's loop: run_ticks_graph(n) replays until every sampled game has finished an episode."""
     from alphafive_amd.engine import SelfPlayEngine
-    sp = SelfPlayEngine(cfg, G, net.select_backend("hip"), device=0, seed=SEED, eval_memo=memo)
+    sp = SelfPlayEngine(cfg, G, net.select_backend("hip"), device=0, seed=SEED, eval_memo=memo, value_f64=value_f64)
     got, replays = {}, 0
     while not all(g in got for g in sample):
         for _ in range(32):
@@ -103,7 +103,7 @@ def _run_pipeline(cfg, G, net, sample, memo, n=16, max_replays=40000):
     return got, ct, ms
 
 
-def _oracle_episodes(cfg, net, games, episodes_per_game):
+def _oracle_episodes(cfg, net, games, episodes_per_game, value_f64=False):
     """-> {game: [(records, extra) per episode]} from OraclePlayers fed by a second handle of the net kernels."""
     S = cfg.board_size
     pv_batch, pv_single = net.select_backend("hip"), net.select_backend("hip")
@@ -113,7 +113,7 @@ def _oracle_episodes(cfg, net, games, episodes_per_game):
     def work(slot, g):
         try:
             orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
-                                      pv_fn=lambda x: ls.eval(slot, x))
+                                      pv_fn=lambda x: ls.eval(slot, x), value_f64=value_f64)
             out[g] = [orc.run() for _ in range(episodes_per_game[g])]
             orc.close()
         except Exception as e:                       # noqa: BLE001  (a dead thread must not leave the others waiting)
@@ -146,15 +146,15 @@ def _compare(raw, orun, S, gamma):
         assert (p.view(np.uint32) == op.view(np.uint32)).all(), tag + ": policy bits at ply %d" % t
 
 
-def _pipeline_vs_oracle(S, sims, upper, G, sample, memo, weights, seed_net=0):
+def _pipeline_vs_oracle(S, sims, upper, G, sample, memo, weights, seed_net=0, value_f64=False):
     from alphafive_amd.network import ResNet
     cfg = make_cfg(board_size=S, simulation_per_step=sims, upper_simulation_per_step=upper)
     net = ResNet(S, device="cuda", seed=seed_net)
     if weights:
         net.load_npz(weights)
-    got, ct, ms = _run_pipeline(cfg, G, net, sample, memo)
+    got, ct, ms = _run_pipeline(cfg, G, net, sample, memo, value_f64=value_f64)
     want = {g: min(len(got[g]), 2 if g == sample[0] else 1) for g in sample}     # the first sampled game: its second episode too
-    oruns, ls = _oracle_episodes(cfg, net, list(sample), want)
+    oruns, ls = _oracle_episodes(cfg, net, list(sample), want, value_f64=value_f64)
     plies = 0
     for g in sample:
         assert [e["seq"] for e in got[g]] == list(range(len(got[g])))
@@ -191,3 +191,11 @@ def test_bench_pipeline_15x15_at_config4_settings_matches_the_oracle(memo):
     assert ct["stalls"] == 0
     if memo:
         assert ms["hits"] > 100
+
+
+def test_bench_pipeline_with_fp64_tree_values_matches_the_pipe_oracle():
+    """`bench.py --pipe-values` / `SelfPlayEngine(value_f64=True)`: the arithmetic of the workers main.py actually runs (values cross a
+    pipe as python floats, networkAPI.py:72, so W and Q are fp64 — af_tick_kernel<2, true>) through the same graph loop and real net,
+    against the oracle's pipe variant (itself pinned on the reference Player behind the reference NetworkAPI, tests/golden/*_pipe.npz)."""
+    ct, _ = _pipeline_vs_oracle(11, 500, 642, 64, [0, 7, 31, 63], dict(log2_buckets=12, max_stones=5), W, value_f64=True)
+    assert ct["terminals"] > 0 and ct["stalls"] == 0
