@@ -802,7 +802,7 @@ def main():
         traffic_net = traffic_tick = None
         traffic_src = None
         pmc = None
-        tp = next((q for q in (os.path.join(REPO, "profiles", "r%d_pmc_hbm_traffic.json" % r) for r in (5, 4, 3)) if os.path.exists(q)),
+        tp = next((q for q in (os.path.join(REPO, "profiles", "r%d_pmc_hbm_traffic.json" % r) for r in (6, 5, 4, 3)) if os.path.exists(q)),
                   os.path.join(REPO, "profiles", "r3_pmc_hbm_traffic.json"))
         tp_name = "profiles/" + os.path.basename(tp)
         if os.path.exists(tp) and deep is None and roof["backend"].startswith("hip") and args.conv_mode == 5:
