@@ -1381,6 +1381,7 @@ struct af_engine {
     int64_t pack_cap = 0;
     std::vector<int32_t> pack_host;
     std::vector<u64> h_ct;
+    unsigned long long* stamps = nullptr;   // af_engine_stamp (allocated on first use; freed with the other allocations)
     bool memo = false;                // af_engine_memo_enable
     bool memo_budget_fixed = false;   // AF_MEMO_BUDGET given: af_engine_set_tick_budget leaves memo_budget alone
     size_t memo_entries = 0;
@@ -1826,6 +1827,29 @@ int af_engine_progress(af_engine* e, void* stream, uint64_t* out) {
 int af_engine_progress_async(af_engine* e, void* stream, uint64_t* out_pinned) {
     if (!e || !out_pinned) return AF_ERR_ARG;
     HIP_OK(hipMemcpyAsync(out_pinned, e->P.progress, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return AF_OK;
+}
+
+// ABI v6: device-clock stamps, so that a kernel's duration can be measured INSIDE a captured graph (ROCm refuses timing events there)
+__global__ void af_stamp_kernel(unsigned long long* stamps, int slot) {
+    if (threadIdx.x == 0) stamps[slot] = wall_clock64();       // s_memrealtime: the device-wide 100-MHz clock
+}
+
+int af_engine_stamp(af_engine* e, void* stream, int32_t slot) {
+    if (!e || slot < 0 || slot >= AF_STAMP_SLOTS) return AF_ERR_ARG;
+    if (!e->stamps) {
+        HIP_OK(hipSetDevice(e->device));
+        int rc = dalloc(e, &e->stamps, (size_t)AF_STAMP_SLOTS);
+        if (rc != AF_OK) return rc;
+    }
+    hipLaunchKernelGGL(af_stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->stamps, (int)slot);
+    HIP_OK(hipGetLastError());
+    return AF_OK;
+}
+
+int af_engine_stamps_async(af_engine* e, void* stream, uint64_t* out_pinned) {
+    if (!e || !out_pinned || !e->stamps) return AF_ERR_ARG;
+    HIP_OK(hipMemcpyAsync(out_pinned, e->stamps, AF_STAMP_SLOTS * 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return AF_OK;
 }
 

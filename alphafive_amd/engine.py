@@ -14,6 +14,7 @@ _LIBPATH = os.environ.get("AF_HIP_LIB") or os.path.join(_PKG, "_lib", "libaf_hip
 MODE_SELFPLAY, MODE_EXTERNAL = 0, 1
 MODE_VALUE_F64 = 0x100       # OR into mode: the reference's pipe path (networkAPI.py:72 float(v)): W, Q fp64
 STATUS_IDLE, STATUS_NEED_EVAL, STATUS_MOVE_DONE, STATUS_YIELD = 0, 1, 2, 3
+STAMP_SLOTS = 64             # af_engine.h AF_STAMP_SLOTS
 BLACK_WIN, WHITE_WIN, DRAW = 1, -1, 0          # utils.py:9-11
 
 CFG_ATTRS = ("board_size", "goal", "simulation_per_step", "upper_simulation_per_step", "init_temp", "gamma",
@@ -82,6 +83,8 @@ def lib():
         L.af_engine_set_tree_w64.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
         L.af_engine_progress.argtypes = [vp, vp, u64p]
         L.af_engine_progress_async.argtypes = [vp, vp, vp]
+        L.af_engine_stamp.argtypes = [vp, vp, C.c_int32]
+        L.af_engine_stamps_async.argtypes = [vp, vp, vp]
         L.af_engine_tick_histogram.argtypes = [vp, vp, u64p, C.c_int32]
         L.af_engine_set_tick_budget.argtypes = [vp, C.c_int32]
         L.af_engine_memo_enable.argtypes = [vp, C.c_int32, C.c_int32]
@@ -274,6 +277,14 @@ class Engine:
         """The 16-byte progress copy without the wait (ABI v4): out_ptr = pinned host memory; stream-ordered, capturable."""
         _check(lib().af_engine_progress_async(self._h, stream, out_ptr), "af_engine_progress_async")
 
+    def stamp(self, slot, stream=None):
+        """Device-clock stamp (ABI v6): a one-wave kernel writes the 100-MHz device clock into slot `slot`; capturable."""
+        _check(lib().af_engine_stamp(self._h, stream, int(slot)), "af_engine_stamp")
+
+    def stamps_async(self, out_ptr, stream=None):
+        """The STAMP_SLOTS stamps -> pinned host memory (uint64[64]), stream-ordered, capturable."""
+        _check(lib().af_engine_stamps_async(self._h, stream, out_ptr), "af_engine_stamps_async")
+
     def tree_dump(self, game):
         cnt = _check(lib().af_engine_tree_dump(self._h, game, 0, None, None, None, None, None, None), "tree_dump")
         keys = np.zeros((cnt, self.KW2), np.uint64)
@@ -409,11 +420,15 @@ class SelfPlayEngine:
         self._graph = None
         self._prog_host, self._prog_events, self._prog_turn, self._prog_replays = None, None, 0, 0
         self.replay_events = []                      # (ticks, start event, end event) of the replays run with timed=True
+        self._graph_stamped, self._stamp_host, self._stamp_event, self._stamp_pending, self.stamp_samples = None, None, None, False, []
 
-    def tick(self):
-        """One simulation step for every game: tree kernel -> leaf batch -> net."""
+    def tick(self, stamp_base=None):
+        """One simulation step for every game: tree kernel -> leaf batch -> net.  stamp_base = s: device-clock stamps in slots s (before
+        the tree kernel), s + 1 (between the two) and s + 2 (after the forward and the memo insert) — Engine.stamp."""
         torch = self.torch
         stream = torch.cuda.current_stream(self.dev).cuda_stream
+        if stamp_base is not None:
+            self.engine.stamp(stamp_base, stream)
         memo = self.engine.memo is not None
         if memo:
             ver = self._weights_version()
@@ -421,6 +436,8 @@ class SelfPlayEngine:
                 self.engine.memo_clear(stream)
                 self._memo_version = ver
         self.engine.tick(self.policy.data_ptr(), self.value.data_ptr(), self.planes.data_ptr(), stream)
+        if stamp_base is not None:
+            self.engine.stamp(stamp_base + 1, stream)
         p, v = self.pv_device(self.planes)
         if p.data_ptr() != self.policy.data_ptr():
             self.policy.copy_(p.reshape(self.G, self.C))
@@ -428,6 +445,8 @@ class SelfPlayEngine:
             self.value.copy_(v.reshape(self.G))
         if memo:
             self.engine.memo_insert(self.policy.data_ptr(), self.value.data_ptr(), stream)
+        if stamp_base is not None:
+            self.engine.stamp(stamp_base + 2, stream)
         self.ticks += 1
 
     def run_ticks(self, n, check_every=0):
@@ -463,19 +482,53 @@ class SelfPlayEngine:
         ver = self._weights_version
         return (int(n), self.engine.params_key(), ver() if ver is not None else None)
 
-    def run_ticks_graph(self, n=16, timed=False):
+    def run_ticks_graph(self, n=16, timed=False, stamped=False):
         """n ticks replayed as ONE HIP graph on the current stream (the tick kernel, the forward's 13 launches with the value
         branch's fork / join, and at the end a 16-byte copy of the engine's progress words into pinned host memory).  Returns at
         once; progress_lagged() reads the words one replay later, so polling never drains the device.  The graph is keyed on
         everything a launch has baked in: n, the engine's by-value parameters (training flag, simulation budget, per-launch select
         budget) and the evaluator's weight version — a change drops it, one eager tick re-packs the weights and the batch is
         captured again (same protocol as Player._search_batch).  A failing capture raises: there is no silent eager fallback.
-        timed=True brackets the replay with HIP timing events on its stream and appends them to self.replay_events."""
+        timed=True brackets the replay with HIP timing events on its stream and appends them to self.replay_events.
+        stamped=True replays a second capture of the same n ticks with three device-clock stamps per tick (Engine.stamp: before the tree
+        kernel, between the two, after the forward) and a copy of the stamps to pinned memory at its end: read_stamps() returns, one
+        replay late, the (tree kernel, forward) durations as they ran INSIDE the graph — timing events cannot be captured on ROCm."""
         torch = self.torch
         if getattr(self, "_weights_version_missing", False):
             raise EngineError("run_ticks_graph: pv_device takes bind_outputs but exposes no weights_version (a replayed graph "
                               "would keep evaluating with stale weights); pass SelfPlayEngine(..., weights_version=lambda: net.version)")
         key = self._graph_key(n)
+        if stamped:
+            if 3 * n > STAMP_SLOTS:
+                raise EngineError("run_ticks_graph(stamped=True): at most %d ticks per replay" % (STAMP_SLOTS // 3))
+            if self._graph_stamped is None or self._graph_stamped[0] != key:
+                self._graph_stamped = None
+                if self._graph is None or self._graph[0] != key:
+                    self.run_ticks_graph(n)               # (the plain capture does the warm-up tick and the allocations)
+                if self._stamp_host is None:
+                    self._stamp_host = torch.zeros(STAMP_SLOTS, dtype=torch.int64, pin_memory=True)
+                    self._stamp_event = torch.cuda.Event()
+                    self.engine.stamp(0, torch.cuda.current_stream(self.dev).cuda_stream)     # (allocates the stamp array: not inside a capture)
+                torch.cuda.synchronize(self.dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    for i in range(n):
+                        self.tick(stamp_base=3 * i)
+                    st = torch.cuda.current_stream(self.dev).cuda_stream
+                    self.engine.stamps_async(self._stamp_host.data_ptr(), st)
+                    self.engine.progress_async(self._prog_host.data_ptr(), st)
+                self.ticks -= n
+                self._graph_stamped = (self._graph_key(n), g, n)
+            if self._stamp_pending:                       # the previous stamped replay's stamps, before this one overwrites them
+                self._collect_stamps()
+            self._graph_stamped[1].replay()
+            self._stamp_event.record(torch.cuda.current_stream(self.dev))
+            self._stamp_pending = True
+            self.ticks += n
+            self._prog_turn ^= 1
+            self._prog_events[self._prog_turn].record(torch.cuda.current_stream(self.dev))
+            self._prog_replays += 1
+            return
         if self._graph is None or self._graph[0] != key:
             self._graph = None
             if self._prog_host is None:
@@ -504,6 +557,19 @@ class SelfPlayEngine:
         self._prog_turn ^= 1
         self._prog_events[self._prog_turn].record(torch.cuda.current_stream(self.dev))
         self._prog_replays += 1
+
+    def _collect_stamps(self):
+        self._stamp_event.synchronize()
+        t = self._stamp_host.numpy().astype(np.int64)[:3 * self._graph_stamped[2]].reshape(-1, 3)
+        self.stamp_samples.append(np.stack([(t[:, 1] - t[:, 0]) * 1e-5, (t[:, 2] - t[:, 1]) * 1e-5], axis=1))     # ms (10-ns ticks)
+        self._stamp_pending = False
+
+    def read_stamps(self):
+        """-> float64[k][2]: (tree kernel ms, forward ms) of every tick of every stamped replay so far, as they ran inside the graph
+        (each interval includes the launch boundaries of the two stamp kernels around it).  Waits for the last stamped replay only."""
+        if self._stamp_pending:
+            self._collect_stamps()
+        return np.concatenate(self.stamp_samples) if self.stamp_samples else np.zeros((0, 2))
 
     def progress_lagged(self):
         """(plies committed, episodes finished) as of the end of the PREVIOUS run_ticks_graph() replay or later: waits for that

@@ -600,7 +600,12 @@ def main():
         stepno["n"] += 1
         while True:
             if use_graph:
-                sp.run_ticks_graph(args.poll, timed=timing["on"])         # returns at once
+                if sample and k == at and 3 * args.poll <= 64:
+                    # one replay per step is the STAMPED capture of the same ticks: three device-clock stamps per tick (before the tree
+                    # kernel, between the two, after the forward) = each kernel's duration as it runs inside the graph
+                    sp.run_ticks_graph(args.poll, stamped=True)
+                else:
+                    sp.run_ticks_graph(args.poll, timed=timing["on"])     # returns at once
                 if sample and k >= at:
                     # the sample that times the two kernels: eager launches bracketed by HIP events on the launch stream, inside
                     # the timed region, issued while the replay above keeps the device busy (no launch latency inside the
@@ -778,6 +783,8 @@ def main():
         net_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_net]))
         net_ms_eager = net_ms
         graph_tick_ms = None
+        stamps = sp.read_stamps() if use_graph else np.zeros((0, 2))
+        derived_net_ms = stamped_tick_ms = None
         if use_graph and sp.replay_events:
             # what the timed region actually runs: the replays, each bracketed by HIP events on its stream.  One tick of a replay =
             # af_tick_kernel + the forward; the tick kernel alone is a single launch whose eager, event-timed samples are what it
@@ -785,7 +792,13 @@ def main():
             # of the FORWARD carry the cost of its fork / join with the value branch's side stream as stream operations — a box-
             # dependent 0-60 us that a graph edge does not have — and are kept as roofline.ms_per_launch_eager_sample.)
             graph_tick_ms = float(np.sum([a.elapsed_time(b) for _, a, b in sp.replay_events]) / np.sum([n_ for n_, _, _ in sp.replay_events]))
-            net_ms = graph_tick_ms - tick_ms
+            derived_net_ms = graph_tick_ms - tick_ms
+            net_ms = derived_net_ms
+            if len(stamps):
+                # r6: MEASURED inside the graph — device-clock stamps (af_engine_stamp, 10-ns ticks) around the forward
+                # of every tick of one replay per step; each interval carries the launch boundaries of the two stamp kernels around
+                # it (~1.5 us each), so it is an upper bound; the derived figure (replay per tick - eager tick kernel) stays beside it
+                stamped_tick_ms, net_ms = float(stamps[:, 0].mean()), float(stamps[:, 1].mean())
         flop_pos = FLOP_PER_POSITION if cfg.board_size == 11 else net.flops_per_position()
         roof = net.roofline_info(pv)
         peak, dtype_name = roof.get("peak_tflops", PEAK_FP32_MFMA_TFLOPS), "f32"
@@ -880,11 +893,15 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": net_tflops / peak,
                          "traffic": traffic_net, "traffic_source": traffic_src, "ms_per_launch": net_ms,
                          "ms_per_launch_eager_sample": net_ms_eager,
-                         "ms_per_launch_source": ("DERIVED: HIP events around every graph replay of the timed region / ticks per replay (the primary "
-                                                  "measurement: time_split.graph_replay_ms_per_tick) - the tick kernel's eager event-timed launch "
-                                                  "duration (samples of 8 at a position that rotates through the step) = the forward as it runs "
-                                                  "inside the graph") if graph_tick_ms else
+                         "ms_per_launch_source": ("MEASURED inside the HIP graph: device-clock stamps (af_engine_stamp: s_memrealtime, 10-ns ticks) before and "
+                                                  "after the forward of every tick of one stamped replay per step (%d ticks stamped; timing events "
+                                                  "cannot be captured on ROCm); includes the launch boundaries of the two stamp kernels (~1.5 us each). "
+                                                  "ms_per_launch_derived = graph replay time per tick - the tick kernel's eager event-timed duration"
+                                                  % len(stamps)) if len(stamps) else
+                                                 ("DERIVED: HIP events around every graph replay / ticks per replay - the tick kernel's eager "
+                                                  "event-timed duration") if graph_tick_ms else
                                                  "HIP events around every eager forward of the timed region",
+                         "ms_per_launch_derived": derived_net_ms,
                          "flop_per_launch": G * flop_pos,
                          "note": "achieved = algorithmic (direct-convolution) FLOPs per launch / launch time; peak = dense MFMA peak of the "
                                  "operand type the kernel issues (fp16: 2.5 PFLOP/s; fp32: 157.3 TFLOP/s)"},
@@ -895,8 +912,9 @@ def main():
                               "note": "SURVEY 8d bound (HBM); PMC (profiles/r1_16) shows the kernel limited by per-game serial latency and fp64 VALU work of the noise generator"},
             "time_split": {"tree_ms_per_tick": tick_ms, "net_ms_per_tick": net_ms,
                            # what a tick costs beyond its two kernels: launch gaps, host polls, the hand-off (<= 5 us)
-                           "outside_kernels_us_per_tick": 1e3 * (1e3 * t / max(1, n_ticks) - tick_ms - net_ms),
+                           "outside_kernels_us_per_tick": 1e3 * (1e3 * t / max(1, n_ticks) - (graph_tick_ms if graph_tick_ms else tick_ms + net_ms)),
                            "graph_replay_ms_per_tick": graph_tick_ms, "net_ms_per_tick_eager_sample": net_ms_eager,
+                           "tree_ms_per_tick_in_graph_stamped": stamped_tick_ms, "ticks_stamped": int(len(stamps)),
                            "tree_ms_max": float(np.max([a.elapsed_time(b) for a, b in ev_tick])),
                            "tree_ms_p50": float(np.median([a.elapsed_time(b) for a, b in ev_tick]))},
             "tick_shape": {"selects_per_game_and_launch_hist": hist["selects"].tolist(),

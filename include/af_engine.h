@@ -195,6 +195,16 @@ int af_engine_progress(af_engine* e, void* stream, uint64_t* out);
  * poll never drains the device (main.py:57-76's loop blocks on its Queue instead: the same role, without the wait). */
 int af_engine_progress_async(af_engine* e, void* stream, uint64_t* out_pinned);
 
+/* ABI v6: device-clock stamps — what a HIP timing event would be if ROCm allowed one inside a captured graph.  af_engine_stamp enqueues
+ * a one-wave kernel that writes the device-wide 100-MHz clock (s_memrealtime, 10-ns ticks) into slot `slot` (0 .. AF_STAMP_SLOTS-1) of the
+ * engine's stamp array; af_engine_stamps_async copies the AF_STAMP_SLOTS slots into pinned host memory, stream-ordered (both capturable).
+ * A driver that replays n x (stamp, af_engine_tick, stamp, forward, stamp) reads each kernel's duration as it runs inside the graph —
+ * including the two launch boundaries the stamp kernels add around it (~1.5 us each): an upper bound of the kernel's own time.
+ * (bench.py: roofline.ms_per_launch; reference: there is nothing to time in genData/player.py — the measurement contract is this task's.) */
+#define AF_STAMP_SLOTS 64
+int af_engine_stamp(af_engine* e, void* stream, int32_t slot);
+int af_engine_stamps_async(af_engine* e, void* stream, uint64_t* out_pinned);
+
 /* tree inspection (tests / Player.tree): nodes of game g in storage order.
  * n has the "w is fp32-typed" flag stripped into f32[]. Returns node count or <0. */
 int af_engine_tree_dump(af_engine* e, int32_t game, int32_t cap, uint64_t* keys, int32_t* sum_n, int32_t* n,

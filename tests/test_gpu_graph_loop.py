@@ -197,3 +197,31 @@ def test_graph_loop_on_the_other_instantiations(board, goal, value_f64):
     assert [(e["game"], e["seq"], e["T"]) for e in _drain(a)] == [(e["game"], e["seq"], e["T"]) for e in _drain(b)]
     a.close()
     b.close()
+
+
+def test_stamped_replay_times_the_kernels_inside_the_graph_and_changes_nothing():
+    """ABI v6 af_engine_stamp: the stamped capture of the loop (three device-clock stamps per tick) is the same computation as the plain
+    one — counters and trees equal an engine that never stamps — and its stamps are ordered, plausible durations."""
+    from alphafive_amd.engine import SelfPlayEngine
+    from alphafive_amd.network import ResNet
+    cfg = make_cfg(simulation_per_step=40, upper_simulation_per_step=60)
+    G = 128
+    nets = [ResNet(11, device="cuda") for _ in range(2)]
+    for nt in nets:
+        nt.load_npz(W)
+    a = SelfPlayEngine(cfg, G, nets[0].select_backend("hip"), device=0, seed=4)
+    b = SelfPlayEngine(cfg, G, nets[1].select_backend("hip"), device=0, seed=4)
+    for r in range(12):
+        a.run_ticks_graph(8, stamped=(r % 3 == 1))
+    st = a.read_stamps()
+    assert st.shape == (4 * 8, 2)
+    assert (st > 0).all() and (st[:, 0] < 5.0).all() and (st[:, 1] < 20.0).all()          # ms: ordered stamps, sane magnitudes
+    assert st[:, 1].mean() > st[:, 0].mean() * 0.5                                       # the forward is not shorter than half a tick kernel
+    b.run_ticks(a.ticks)
+    a.check(), b.check()
+    assert a.counters() == b.counters() and a.progress() == b.progress()
+    ta, tb = a.engine.tree_dump(5), b.engine.tree_dump(5)
+    for k in ("keys", "sum_n", "n"):
+        assert (ta[k] == tb[k]).all()
+    assert ta["w"].tobytes() == tb["w"].tobytes()
+    a.close(), b.close()
