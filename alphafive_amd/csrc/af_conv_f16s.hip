@@ -95,19 +95,16 @@ template <class G> struct Hx {
 constexpr int kS = 11, kPIX = 144, kNPIX = kS * kS;
 constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB;
 
-// Build-time variants (A/B'ed by tools/probe_f16s_ab.py on 4096 positions, r3_06 / r3_08; the defaults are what measured best):
-//   AF_F16S_NT_LOAD    1: the LDS-DMA slab loads carry the nt (streaming) hint: 1.385 -> 1.357 ms per forward
-//   AF_F16S_MAIN_FIRST 1: a position's 3x3 slabs stream before the slabs of the folded 1x1 projection: 1.357 -> 1.352 ms, and
-//                         |dv| 1.5e-6 -> 8.7e-7 (the small projection terms are added last)
-//   AF_F16S_NT_STORE   1: nt hint on the activation stores: no gain (1.421 vs 1.421)
+// Choices that were build-time A/B switches until r6 (tools/probe_f16s_ab.py on 4096 positions, r3_06 / r3_08), now fixed in the source:
+//   the LDS-DMA slab loads carry the nt (streaming) hint: 1.385 -> 1.357 ms per forward (the other scope-bit codes measured no better);
+//   a position's 3x3 slabs stream BEFORE the slabs of the folded 1x1 projection: 1.357 -> 1.352 ms, and |dv| 1.5e-6 -> 8.7e-7 (the
+//   small projection terms are added last; the other order also moved |dp| from 6.0e-6 to 8.1e-6);
+//   no nt hint on the activation stores: no gain (1.421 vs 1.421).
 // Tried and removed (r3): the lo halves of the split by v_fma_mixlo/mixhi_f16 (one instruction per element instead of convert back,
 // subtract, convert): same bits, 1.433 vs 1.436 ms (profiles/r3_15).  Leaving the epilogue's stores in flight across the next position's first LDS-DMA waits (vmcnt counts
 // stores too and a wave's operations retire in issue order — tools/probes/vmcnt_order.hip — so the counts can be relaxed by the
 // number of younger stores): correct, 1.421 vs 1.421 ms — the waits do not sit on store acknowledgements; the epilogue is
 // VALU-bound (profiles/r3_07).  Stores issued by hand in an asm block: corrupt activations (a hazard the compiler cannot see).
-#ifndef AF_F16S_NT_STORE
-#define AF_F16S_NT_STORE 0
-#endif
 // (A/B record r3_43, removed from the source in r6: m0 declared clobbered by the LDS-DMA asm instead of saved / restored around it:
 //  -0.2 %, but hipcc warns that a clobber of the reserved m0 "may not be preserved")
 // (r3_43, rejected: requesting past the end of the slab stream — the last position again — so that no branch surrounds the LDS-DMA
@@ -118,12 +115,6 @@ constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB
 #ifndef AF_F16S_VW
 #define AF_F16S_VW 128          // architectural VGPRs given to weight fragments
 #endif
-#ifndef AF_F16S_NT_LOAD
-#define AF_F16S_NT_LOAD 1
-#endif
-#ifndef AF_F16S_MAIN_FIRST
-#define AF_F16S_MAIN_FIRST 1
-#endif
 //   AF_F16S_ZPAD       1: the lanes of a pixel tile that lie past the board (7 of 128 at 11x11, 31 of 128 in the second half of
 //                         a 15x15 board) read their B fragments from the all-zero LDS region instead of a real pixel's: the
 //                         results of those columns are discarded either way, but zero operands toggle fewer MFMA bits and the
@@ -132,13 +123,7 @@ constexpr uint32_t kRowB = kPIX * 16u, kHalfB = 4u * kRowB, kSlabB = 2u * kHalfB
 #define AF_F16S_ZPAD 1
 #endif
 
-__device__ __forceinline__ void st16(void* gdst, const h8& v) {
-#if AF_F16S_NT_STORE
-    __builtin_nontemporal_store(v, reinterpret_cast<h8*>(gdst));
-#else
-    *reinterpret_cast<h8*>(gdst) = v;
-#endif
-}
+__device__ __forceinline__ void st16(void* gdst, const h8& v) { *reinterpret_cast<h8*>(gdst) = v; }
 
 // Write-through ("sc1": agent scope) stores for data that another workgroup of the SAME launch reads (the roles of af_small_forward_f16s):
 // the line goes through this XCD's L2 to memory, so the consumer — on whatever XCD — needs no cache-wide release / acquire, only the
@@ -173,21 +158,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // LDS-DMA: 16 bytes per lane from global memory into LDS at (wave-uniform lds_dst) + lane*16; counted on vmcnt.
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
     unsigned keep;
-    // cache policy of the slab loads (AF_F16S_NT_LOAD: 0 default, 1 nt; 2.. = A/B codes for the scope bits)
-#if AF_F16S_NT_LOAD == 0
-#define AF_F16S_LOAD_POLICY ""
-#elif AF_F16S_NT_LOAD == 1
-#define AF_F16S_LOAD_POLICY " nt"
-#elif AF_F16S_NT_LOAD == 2
-#define AF_F16S_LOAD_POLICY " sc1"
-#elif AF_F16S_NT_LOAD == 3
-#define AF_F16S_LOAD_POLICY " sc1 nt"
-#elif AF_F16S_NT_LOAD == 4
-#define AF_F16S_LOAD_POLICY " sc0 sc1 nt"
-#else
-#define AF_F16S_LOAD_POLICY " sc0 nt"
-#endif
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" AF_F16S_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
@@ -392,14 +363,11 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
     const unsigned long long wall_entry = wall_clock64();
 #endif
 
-    // slab j of a position: the NSP slabs of the projection input first, then the NSM slabs of the 3x3 input (the other
-    // order — long slabs first, so that the epilogue's stores have more time before the next wait on vmcnt — measured
-    // 1.58 vs 1.55 ms per forward and moved |dp| from 6.0e-6 to 8.1e-6)
+    // slab j of a position: the NSM slabs of the 3x3 input first, then the NSP slabs of the projection input
     auto slab_src = [&](int qq, int j) -> const char* {             // (qq: pseudo-position)
         const int p_ = (HV == 1 || HSEL >= 0) ? qq : qq / HV;
         const int p = (A.abl & 0x1000) ? (p_ & 127) : p_;   // abl bit 12 (profiling): slab LOADS addressed modulo 128 positions (cache-resident ring); bit 3: the stores
-        if (AF_F16S_MAIN_FIRST) return (j < NSM ? A.in + ((size_t)p * NSM + j) * kSlabH : A.in2 + ((size_t)p * NSP + (j - NSM)) * kSlabH) + wsrc;
-        return (j < NSP ? A.in2 + ((size_t)p * NSP + j) * kSlabH : A.in + ((size_t)p * NSM + (j - NSP)) * kSlabH) + wsrc;
+        return (j < NSM ? A.in + ((size_t)p * NSM + j) * kSlabH : A.in2 + ((size_t)p * NSP + (j - NSM)) * kSlabH) + wsrc;
     };
     // piece wv + 4k of a slab, k = 0..NPC-1: every wave issues exactly NPC LDS-DMA instructions (1 KB each) per slab — one per
     // item, the rest behind the slab's last item — which is what lets the counted "s_waitcnt vmcnt" in front of each barrier
@@ -621,8 +589,8 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
 #define AF_FIRST_ITEM(slot)                                                                                      \
     _Pragma("unroll") for (int jj = 0; jj < NT; ++jj) {                                                          \
         const uint32_t c_ = (AF_F16S_ZPAD && !ok[jj]) ? zb[jj] : lb[jj] + (slot), l_ = edgeL[jj] ? zb[jj] : c_, r_ = edgeR[jj] ? zb[jj] : c_; \
-        fr[0][jj][0] = rd(smem, NSP > 0 && !AF_F16S_MAIN_FIRST, 0, 0, c_, l_, r_);                               \
-        fr[0][jj][1] = rd(smem, NSP > 0 && !AF_F16S_MAIN_FIRST, 0, 1, c_, l_, r_);                               \
+        fr[0][jj][0] = rd(smem, false, 0, 0, c_, l_, r_);                                                        \
+        fr[0][jj][1] = rd(smem, false, 0, 1, c_, l_, r_);                                                        \
     }
     if (XPOS) { AF_FIRST_ITEM(0u) }
 #ifdef AF_F16S_TIMING
@@ -656,14 +624,14 @@ __device__ __forceinline__ void f16s_body(const F16sArgs& A, char* smem, const i
 #pragma clang loop unroll(full)
         for (int j = 0; j < SPP; ++j) {
             // this slab / the next slab of the stream: a projection slab?  (ms = index among the position's 3x3 slabs)
-            const bool proj = AF_F16S_MAIN_FIRST ? j >= NSM : j < NSP;
-            const bool nproj = AF_F16S_MAIN_FIRST ? (j + 1) % SPP >= NSM : (j + 1) % SPP < NSP;
-            const int ms = AF_F16S_MAIN_FIRST ? j : j - NSP, pslab = AF_F16S_MAIN_FIRST ? j - NSM : j;
+            const bool proj = j >= NSM;
+            const bool nproj = (j + 1) % SPP >= NSM;
+            const int ms = j, pslab = j - NSM;
             const int NI = proj ? ITP : ITM;
             // ibase: the slab's first item in the weight array (packed projection items first); seq: its running number within the
             // position (fragment double-buffer parity)
             const int ibase = proj ? pslab * ITP : NSP * ITP + ms * ITM;
-            const int seq = AF_F16S_MAIN_FIRST ? (proj ? NSM * ITM + pslab * ITP : ms * ITM) : ibase;
+            const int seq = proj ? NSM * ITM + pslab * ITP : ms * ITM;
             // slab t + kDist of the stream: j is static (the loop is unrolled), so which position / slab that is costs no division
             const int npos = qpos + ((j + kDist) / SPP) * gxw;
             const bool more = npos < nq && !(A.abl & 1);
@@ -1065,7 +1033,7 @@ __global__ __launch_bounds__(256) void af_corner_f16s(CornerArgs A) {
     for (int h = 0; h < KS; ++h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[h][r] = 0.0f; if (XACC) acx[h][r] = 0.0f; }
-    static_assert(AF_F16S_MAIN_FIRST, "the corner kernel restates the main kernel's slab order: 3x3 slabs, then the projection's");
+    // (the corner kernel restates the main kernel's slab order: 3x3 slabs, then the projection's)
     // step t -> (k-half, A fragment, B unit): the main kernel's order (slab, k-step, tap; the projection's slabs last)
     const uint4* const wbase = A.w + (size_t)tile * KS * NIT * 2 * 64 + lane;
     // B operands: the compact copy the half-1 workgroups of af_conv_f16s_h15 made while the slabs were in LDS:

@@ -227,3 +227,16 @@ def test_single_launch_small_batch_forward_inside_a_hip_graph():
         assert torch.equal(h.policy[:3], p0) and torch.equal(h.value[:3], v0)
     assert h.small_forward_error() == 0
     h.close()
+
+
+def test_forward_output_digests_are_pinned():
+    """A change of ANY bit of the forward's arithmetic must be a decision, not an accident: CRC32 of policy and value on fixed inputs
+    (tools/forward_digest.py; 11x11 alphaFive-6960 at batch 600 / 5 — the batched kernels / the single-launch roles — and 15x15
+    random init at 300 / 3).  The digests were recorded on the r6 tree BEFORE its source clean-ups (folded build switches, pruned
+    variants) and are unchanged by them; the engine-vs-oracle tests use the same kernels on both sides and could not see such a change."""
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import forward_digest
+    assert forward_digest.digests() == {"S11_B600": "4f50b3f7d08132dc", "S11_B5": "441e8ce5d7f1f336",
+                                        "S15_B300": "75d9f0dcac1b2d1d", "S15_B3": "57cc8bcb0af5cd8e"}
