@@ -1997,6 +1997,10 @@ int f16s_create(f16s_net** out, int board_size, int max_batch, int device, const
     const int halves = s11 ? 1 : 2;
     const size_t slab_bytes = s11 ? Lay<Geo<11>>::kSlabH : Lay<Geo<15>>::kSlabH;
     FS_HIP_OK(hipDeviceGetAttribute(&n->ncu, hipDeviceAttributeMultiprocessorCount, device));
+    if (const char* e = getenv("AF_F16S_NCU")) {      // profiling only (tools/probe_power_bound.py): persistent workgroups of a launch = CUs it may occupy
+        const int v = atoi(e);
+        if (v >= 8 && v <= n->ncu) n->ncu = v / 8 * 8;
+    }
     int rc = 0;
     auto get = [&](const std::string& k) -> const std::vector<float>& { return V.at(k); };
     rc = dev_upload(n->allocs, &n->stem_w, get("bone/conv1/kernel").data(), 75 * 32 * 4);
