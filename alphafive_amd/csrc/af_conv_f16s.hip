@@ -2187,6 +2187,10 @@ static int launch_layer(f16s_net* n, hipStream_t st, int li, const char* in, con
     if (head >= 0) { a.hw = n->hcw[head]; a.hbias = n->hcb[head]; a.hx = n->hx[head]; a.inv_scale_h = n->hc_inv[head]; }
     a.in = in; a.in2 = in2; a.w = n->w[li]; a.bias = n->bias[li]; a.out = out; a.out32 = out32;
     a.inv_scale = n->inv_scale[li]; a.batch = batch; a.WP = WP; a.PP = PP; a.abl = (n->abl & 0xf0ff) | (li << 8); a.gx0 = 0; a.stash = n->stash;
+    {   // profiling only: AF_F16S_ABL_LAYERS = bit mask of the layers the traffic-ablation bits (1, 2, 4, 8, 4096) apply to (default: all)
+        static const int mask = [] { const char* e = getenv("AF_F16S_ABL_LAYERS"); return e ? (int)strtol(e, nullptr, 0) : 0x3ff; }();
+        if (!((mask >> li) & 1)) a.abl &= ~0x100f;
+    }
     a.w2 = nullptr; a.bias2 = nullptr; a.inv_scale2 = 1.0f;
     a.pw = n->pw[li]; a.pbuf = n->pbuf[li / 2]; a.inv_scale_p = n->inv_scale_p[li];
     return n->S == 11 ? launch_layer_g<Geo<11>>(n, st, li, a, head) : launch_layer_g<Geo<15>>(n, st, li, a, head);
