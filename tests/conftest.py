@@ -38,3 +38,16 @@ def cfg_from_golden(z):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def run_in_threads(fn, items, workers=None):
+    """fn(item) for every item on host threads (the C oracle runs outside the GIL: ctypes.CDLL calls release it, and every
+    OraclePlayer owns its handle), results in order; the first exception is re-raised.  The GPU tests' oracle replays are
+    per-game independent, and the GPU boxes have many more cores than one."""
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    if not items:
+        return []
+    n = workers or min(len(items), len(os.sched_getaffinity(0)))
+    with ThreadPoolExecutor(max_workers=max(1, n)) as ex:
+        return list(ex.map(fn, items))

@@ -10,7 +10,7 @@ import pytest
 
 import oracle
 import pseudonet
-from conftest import make_cfg
+from conftest import make_cfg, run_in_threads
 
 pytestmark = pytest.mark.gpu
 SALT, PEAK, SEED = 777, 8192, 42
@@ -72,11 +72,13 @@ def test_config2_full_size_steady_state_parity_invariants_and_sharding():
         assert [e["seq"] for e in eps] == list(range(len(eps)))
     assert hist["selects"][9:].sum() > 0                         # deep simulations happened; the per-launch budget bounds terminal chains
     # bit-exact complete episodes vs the oracle: 8 sampled games, every episode each of them finished
-    for g in (0, 1, 777, 1234, 2048, 3000, 4000, G - 1):
+    def replay(g):                                               # (one host thread per sampled game)
         orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
                                   pseudo_salt=SALT, pseudo_peak=PEAK)
         for raw in got[g][:2 if g in (0, G - 1) else 1]:
             _assert_episode_equals_oracle(raw, orc, 11, cfg.gamma)
+
+    run_in_threads(replay, (0, 1, 777, 1234, 2048, 3000, 4000, G - 1))
     # shard invariance (the single-GPU form of SURVEY §8e's check: an N-GPU run = N independent shards)
     sp2 = SelfPlayEngine(cfg, 256, lambda x: pseudonet.pseudonet_torch(x, SALT, PEAK), device=0, seed=SEED, first_game_id=G - 256)
     got2 = _play_until_every_game_finished(sp2, 256, max_rounds=200)
@@ -98,10 +100,12 @@ def test_config4_15x15_steady_state_episodes_match_oracle():
     ct = sp.counters()
     sp.close()
     assert len(got) == G and ct["collector_runs"] > 0 and ct["stalls"] == 0
-    for g in (0, 100, G - 1):
+    def replay(g):
         orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=SEED, game_id=g,
                                   pseudo_salt=SALT, pseudo_peak=PEAK)
         _assert_episode_equals_oracle(got[g][0], orc, 15, cfg.gamma)
+
+    run_in_threads(replay, (0, 100, G - 1))
 
 
 def test_config4_full_size_15x15_invariants_oracle_and_sharding():
@@ -181,14 +185,15 @@ def test_config4_full_size_15x15_invariants_oracle_and_sharding():
 
 def test_every_game_of_a_512_game_engine_equals_the_oracle():
     """not a sample — every game of a 512-game engine at configs[1]'s settings (11x11, 500 / 642), first_game_id
-    3584 (the last 512 ids of the 4096-game bench engine; a game's tree depends on its id only), each first episode (and every
-    second one that exists) replayed by the C oracle on the host cores (tools/parity_sweep_fullsize.py; the 4096-game run of the
-    same sweep is profiles/r5_40)."""
+    3584 (the last 512 ids of the 4096-game bench engine; a game's tree depends on its id only), each first episode (and, for
+    every 8th game, the second one too if it exists: an episode that starts from a restarted store) replayed by the C oracle on
+    the host cores (tools/parity_sweep_fullsize.py; the 4096-game run of the same sweep, two episodes of every game, is
+    profiles/r5_40)."""
     import sys
     from conftest import REPO
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import parity_sweep_fullsize as sweep
-    rep = sweep.sweep(G=512, board=11, sims=500, upper=642, memo=False, first_game_id=3584)
+    rep = sweep.sweep(G=512, board=11, sims=500, upper=642, memo=False, first_game_id=3584, second_every=8)
     print(rep)
     assert rep["mismatches"] == 0, rep["first_mismatches"]
     assert rep["episodes_compared_with_the_oracle"] >= 512 and rep["plies_compared"] > 512 * 9

@@ -6,7 +6,7 @@ import pytest
 
 import oracle
 import pseudonet
-from conftest import make_cfg
+from conftest import run_in_threads, make_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -210,10 +210,10 @@ def test_selfplay_episodes_match_oracle(S, goal, sims, upper, G, node_cap):
         if sum(len(v) for v in got.values()) >= want and all(len(got.get(g, [])) >= 1 for g in range(G)):
             break
     assert all(len(got.get(g, [])) >= 1 for g in range(G)), "some games never finished"
-    checked = 0
-    for g in range(0, G, max(1, G // 12)):
+    def replay(g):                                   # one game's episodes, in order, on its own oracle player (a host thread each)
         orc = oracle.OraclePlayer(cfg, training=True, rng_mode=oracle.RNG_PHILOX, seed=seed, game_id=first + g,
                                   pseudo_salt=salt, pseudo_peak=peak)
+        n = 0
         for raw in got[g]:
             orec, extra = orc.run()
             assert raw["T"] == len(orec), f"game {g} seq {raw['seq']}"
@@ -224,7 +224,10 @@ def test_selfplay_episodes_match_oracle(S, goal, sims, upper, G, node_cap):
             for (s, p, la, v, w), (os_, op, ola, ov, ow) in zip(rec, orec):
                 assert s == os_ and la == ola and v == ov and w == ow
                 assert (p.view(np.uint32) == op.view(np.uint32)).all()
-            checked += 1
+            n += 1
+        return n
+
+    checked = sum(run_in_threads(replay, range(0, G, max(1, G // 12))))
     assert checked >= 6
     ct = sp.counters()
     assert ct["episodes"] >= len(got)

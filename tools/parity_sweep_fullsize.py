@@ -18,7 +18,7 @@ SALT, PEAK, SEED = 777, 8192, 42
 
 
 def check_game(item):
-    g, eps, board, sims, upper = item
+    g, eps, board, sims, upper = item                 # (eps: the episodes to compare, already cut to length)
     import oracle
     from conftest import make_cfg
     from test_gpu_fullsize import _assert_episode_equals_oracle
@@ -34,7 +34,7 @@ def check_game(item):
     return g, n, None
 
 
-def sweep(G=4096, board=11, sims=500, upper=642, memo=False, procs=None, first_game_id=0):
+def sweep(G=4096, board=11, sims=500, upper=642, memo=False, procs=None, first_game_id=0, second_every=1):
     import pseudonet
     from conftest import make_cfg
     from alphafive_amd.engine import SelfPlayEngine
@@ -52,7 +52,10 @@ def sweep(G=4096, board=11, sims=500, upper=642, memo=False, procs=None, first_g
     assert len(got) == G, "some games never finished"
     procs = procs or len(os.sched_getaffinity(0))
     t1 = time.time()
-    items = [(first_game_id + g, eps, board, sims, upper) for g, eps in sorted(got.items())]
+    # the first episode of every game; the second one (if finished) of every `second_every`-th game
+    items = [(first_game_id + g, eps[:2 if g % second_every == 0 else 1], board, sims, upper) for g, eps in sorted(got.items())]
+    # (processes, not threads: 256 host threads on the ctypes oracle measured 74 s against 46 s for 256 spawned processes — the players'
+    # Python glue serialises on the GIL; the sweep's floor is its longest game, ~40 s for a 121-ply game of the pseudo-net)
     with mp.get_context("spawn").Pool(procs) as pool:
         res = pool.map(check_game, items, chunksize=max(1, min(16, G // (4 * procs))))
     bad = [r for r in res if r[2]]
@@ -60,7 +63,7 @@ def sweep(G=4096, board=11, sims=500, upper=642, memo=False, procs=None, first_g
             "episodes_finished": int(ct["episodes"]),
             "episodes_compared_with_the_oracle": int(sum(r[1] for r in res)), "games_with_two_episodes_compared": sum(r[1] == 2 for r in res),
             "mismatches": len(bad), "first_mismatches": [(r[0], r[2][:120]) for r in bad[:5]],
-            "plies_compared": int(sum(sum(e["T"] for e in eps[:2]) for eps in got.values())),
+            "plies_compared": int(sum(sum(e["T"] for e in it[1]) for it in items)),
             "memo_stats": ms, "gpu_s": round(t_gpu, 1), "oracle_s": round(time.time() - t1, 1), "oracle_processes": procs}
 
 
